@@ -1,0 +1,194 @@
+/*
+ * radnet_hip.h -- C ABI of libradnet_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * Faster R-CNN train / predict hot path of rock-art-radnet.
+ *
+ * The reference has NO native layer: everything below replaces work it hands to the TensorFlow
+ * runtime (Keras graph in faster_rcnn/base_models/resnet50.py, rpn.py:12-66, RoiPoolingConv.py,
+ * FixedBatchNormalization.py, losses.py, keras Adam) or does in single-threaded NumPy/Python
+ * (rpn.py:68-455, utils.py:554-822).  Each entry point cites the reference lines it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch-ROCm tensor.data_ptr());
+ *     the library never allocates or frees caller-visible memory;
+ *   - work is enqueued on the hipStream_t given to radnet_create(); calls return immediately;
+ *   - activations are NHWC fp32; conv weights are [K = kh*kw*cin][N = cout] row-major (the Keras
+ *     HWIO kernel flattened), dense weights [in][out];
+ *   - return value 0 = ok, negative = error; radnet_last_error() gives the message;
+ *   - one context per thread / stream (no internal locking).
+ */
+#ifndef RADNET_HIP_H
+#define RADNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct radnet_ctx radnet_ctx;
+
+#define RADNET_OK 0
+#define RADNET_ERR_ARG (-1)
+#define RADNET_ERR_HIP (-2)
+#define RADNET_ERR_UNSUPPORTED (-3)
+
+/* ---- context ------------------------------------------------------------------------------ */
+int radnet_create(int device, void* hip_stream, radnet_ctx** out);
+void radnet_destroy(radnet_ctx* ctx);
+const char* radnet_last_error(radnet_ctx* ctx);
+int radnet_sync(radnet_ctx* ctx);
+int radnet_version(void);
+/* Scratch the library may use for split-K partial sums (caller-owned, >= bytes). */
+int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);
+/* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
+ * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
+ * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd,1 dgrad,2 wgrad). */
+int radnet_timing_enable(radnet_ctx* ctx, int enable);
+int radnet_timing_read(radnet_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops);
+int radnet_timing_reset(radnet_ctx* ctx);
+
+/* ---- convolution as implicit GEMM on fp32 MFMA ----------------------------------------------
+ * Replaces keras Conv2D / TimeDistributed(Conv2D) + FixedBatchNormalization + Add + Activation
+ * (resnet50.py:41-147,183-186; rpn.py:41-64; FixedBatchNormalization.py:59-85) and their TF
+ * autodiff gradients.  One descriptor describes the FORWARD convolution; dgrad / wgrad reuse it.
+ *
+ *   forward :  y[m][n] = act( (sum_k im2col(x)[m][k] * w[k][n]) * scale[n] + shift[n] + addend[m][n] )
+ *   dgrad   :  dx[p][c] = ( sum_{kh,kw,n} (dy*gscale)[..][n] * w[(kh,kw,c)][n] + addend[p][c] ) masked
+ *              by mask[p][c] > 0   (stride 1 only; ReLU backward of the producer fused as the mask)
+ *   wgrad   :  dw[k][n] (+)= sum_m im2col(x)[m][k] * (dy*gscale)[m][n];  db[n] via radnet_colsum
+ */
+typedef struct radnet_conv_desc {
+  const float* x;        /* forward input  [nb][h][w][c]                                   */
+  const float* w;        /* weights        [kh*kw*c][ldw]                                  */
+  float* y;              /* forward output [nb*oh*ow][ldy]                                 */
+  const float* scale;    /* per-output-channel scale (frozen BN: gamma/sqrt(var+eps)) or 0 */
+  const float* shift;    /* per-output-channel shift (bias and BN shift folded) or 0       */
+  const float* addend;   /* residual branch [m][ld_add] or 0                               */
+  int32_t nb, h, w_, c;  /* input geometry                                                 */
+  int32_t oh, ow;        /* output geometry                                                */
+  int32_t kh, kw, stride, pad_t, pad_l;
+  int32_t n;             /* output channels                                                */
+  int32_t ldw, ldy, ld_add;
+  int32_t act;           /* 0 none, 1 relu, 2 sigmoid on columns [0,act_cols) / linear rest */
+  int32_t act_cols;
+  /* backward-only fields */
+  const float* dy;       /* gradient w.r.t. y (post-activation mask already applied) [m][ld_dy] */
+  const float* gscale;   /* per-output-channel factor applied to dy on load (BN scale) or 0 */
+  float* dx;             /* dgrad output [nb*h*w][ld_dx]                                   */
+  const float* dx_add;   /* added to dx before masking (residual-path gradient) or 0       */
+  const float* dx_mask;  /* dx zeroed where dx_mask <= 0 (producer's ReLU) or 0            */
+  float* dw;             /* wgrad output [kh*kw*c][ldw]                                    */
+  int32_t ld_dy, ld_dx, ld_dx_add, ld_dx_mask;
+  int32_t dw_accumulate; /* 1: dw += (buffer pre-zeroed / holds other contributions)       */
+} radnet_conv_desc;
+
+int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d);
+int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
+int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
+
+/* out[n] (+)= sum_m g[m][n] * gscale[n]   (bias gradients) */
+int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t n, int32_t ld, const float* gscale,
+                  float* out, int32_t accumulate);
+
+/* ---- pooling / RoI crop-resize ------------------------------------------------------------- */
+/* MaxPooling2D k x k / stride s 'valid' (resnet50.py:188: 3,2; VGG16 blocks: 2,2) */
+int radnet_maxpool_fwd(radnet_ctx* ctx, const float* x, float* y, int32_t nb, int32_t h, int32_t w, int32_t c,
+                       int32_t k, int32_t s);
+/* RoiPoolingConv.call (RoiPoolingConv.py:48-88): int-cast RoI, clamped crop, TF1 legacy bilinear
+ * resize to ps x ps.  rois: [r][4] fp32 (x,y,w,h) in feature-map units.  y: [r][ps][ps][c]. */
+int radnet_roi_resize_fwd(radnet_ctx* ctx, const float* fmap, int32_t h, int32_t w, int32_t c, const float* rois,
+                          int32_t r, int32_t ps, float* y);
+/* gradient w.r.t. the feature map (scatter-add; dfmap must be zeroed by the caller) */
+int radnet_roi_resize_bwd(radnet_ctx* ctx, const float* dy, int32_t h, int32_t w, int32_t c, const float* rois,
+                          int32_t r, int32_t ps, float* dfmap);
+/* TimeDistributed(AveragePooling2D((7,7))) + Flatten (resnet50.py:260-261): [r][hw][c] -> [r][c] */
+int radnet_avgpool_fwd(radnet_ctx* ctx, const float* x, int32_t r, int32_t hw, int32_t c, float* y);
+/* dx[r][p][c] = (y_act[r][p][c] > 0) ? dfeat[r][c] / hw : 0  (avg-pool backward fused with the ReLU mask) */
+int radnet_avgpool_bwd_relu(radnet_ctx* ctx, const float* dfeat, const float* y_act, int32_t r, int32_t hw, int32_t c,
+                            float* dx);
+
+/* ---- classifier dense heads (resnet50.py:263-279) -------------------------------------------
+ * w: [k][ldw] with the class columns first then the 4*(nc-1) regression columns; b: [nc+nreg].
+ * out_cls = softmax(feat @ w[:, :nc] + b), out_regr = feat @ w[:, nc:] + b. */
+int radnet_dense_heads_fwd(radnet_ctx* ctx, const float* feat, int32_t r, int32_t k, const float* w, int32_t ldw,
+                           const float* b, int32_t nc, int32_t nreg, float* out_cls, float* out_regr);
+/* dz: [r][nc+nreg] gradient w.r.t. the pre-softmax logits / regression outputs.
+ * Writes dw [k][ldw], db [nc+nreg], dfeat [r][k]. */
+int radnet_dense_heads_bwd(radnet_ctx* ctx, const float* feat, const float* dz, int32_t r, int32_t k, const float* w,
+                           int32_t ldw, int32_t nout, float* dw, float* db, float* dfeat);
+
+/* ---- losses (losses.py) ----------------------------------------------------------------------
+ * RPN (losses.py:16-66): pred [m][ld_pred] holds the sigmoid class scores in columns [0,A) and the
+ * regression outputs in [A,5A) (the fused head GEMM's layout); y_cls [m][2A], y_regr [m][8A].
+ * losses[0..1] = (cls, regr).  dz [m][ld_dz]: gradient w.r.t. the PRE-activation outputs, same
+ * column layout (sigmoid' folded in), columns >= 5A zeroed.
+ * bce_mode 0: K.binary_crossentropy argument order as executed under Keras 2 (target=y_pred,
+ * output=y_true) -- what the reference runs; 1: textbook BCE(y_true, clip(p)). */
+int radnet_rpn_loss(radnet_ctx* ctx, const float* pred, int32_t ld_pred, const float* y_cls, const float* y_regr,
+                    int32_t m, int32_t a, int32_t bce_mode, float* dz, int32_t ld_dz, float* losses,
+                    double* scratch8);
+/* Detector (losses.py:69-95): p_cls [r][nc] softmax, p_regr [r][nreg], y1 [r][nc], y2 [r][2*nreg].
+ * losses[0..2] = (cls, regr, accuracy).  dz [r][nc+nreg] w.r.t. logits / regression outputs. */
+int radnet_det_loss(radnet_ctx* ctx, const float* p_cls, const float* p_regr, const float* y1, const float* y2,
+                    int32_t r, int32_t nc, int32_t nreg, float* dz, float* losses);
+
+/* ---- optimizer: keras.optimizers.Adam over one flat arena (train.py:236-252) ----------------- */
+int radnet_adam_step(radnet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int32_t t, float lr,
+                     float beta1, float beta2, float eps, float grad_scale);
+
+/* ---- proposal decode + greedy NMS (rpn.py:68-172, 299-344, 380-455), fp64 ---------------------
+ * pred: fused head output [rows*cols][ld_pred] (scores in [0,A), regression in [A,5A)).
+ * anchor_wh: host array [A][2] of anchor (w,h) in feature-map units.
+ * out_boxes [max_boxes][4] int64 (x1,y1,x2,y2), out_probs [max_boxes] fp32, out_count[1] int32.
+ * ws: device scratch of >= radnet_proposals_ws_bytes(rows*cols*A) bytes. */
+uint64_t radnet_proposals_ws_bytes(int64_t n_anchors_total);
+int radnet_rpn_to_roi(radnet_ctx* ctx, const float* pred, int32_t ld_pred, int32_t rows, int32_t cols, int32_t a,
+                      const double* anchor_wh_host, double std_scaling, int32_t use_regr, double overlap_thresh,
+                      int32_t max_boxes, int64_t* out_boxes, float* out_probs, int32_t* out_count, void* ws);
+/* Generic greedy NMS on n boxes [n][4] fp64 xyxy + probs fp32 (rpn.py:380-455).  out_idx [max_boxes]
+ * indices into the input.  Malformed boxes (x1>=x2 or y1>=y2) set out_count to -1 (the reference asserts). */
+int radnet_nms(radnet_ctx* ctx, const double* boxes, const float* probs, int32_t n, double overlap_thresh,
+               int32_t max_boxes, int32_t* out_idx, int32_t* out_count, void* ws);
+
+/* ---- anchor targets: utils.calc_region_props before the random subsampling (utils.py:585-766) --
+ * gt [g][4] fp64 (x1,y1,x2,y2) in SOURCE-image pixels, gt_is_bg [g].  anchor_sizes host [ns],
+ * anchor_ratios host [nr][2].  Outputs (A = ns*nr): valid, overlap uint8 [A][fh][fw] (the NCHW order
+ * the host subsampler indexes), regr fp64 [fh][fw][4A], best_anchor int32 [g][4] (jy,ix,ratio,size)
+ * or -1, n_for_gt int32 [g].  scratch: >= 8*g bytes. */
+int radnet_anchor_targets(radnet_ctx* ctx, const double* gt, const int32_t* gt_is_bg, int32_t g, int32_t width,
+                          int32_t height, int32_t rw, int32_t rh, int32_t fw, int32_t fh, const double* anchor_sizes_host,
+                          int32_t ns, const double* anchor_ratios_host, int32_t nr, double rpn_stride,
+                          double max_overlap, uint8_t* valid, uint8_t* overlap, double* regr, int32_t* best_anchor,
+                          int32_t* n_for_gt, void* scratch);
+/* utils.py:815-816 + 475-478: y_cls [fh][fw][2A] = [valid || overlap], y_regr [fh][fw][8A] =
+ * [repeat(overlap,4) || regr*std_scaling], fp32 NHWC. */
+int radnet_anchor_targets_pack(radnet_ctx* ctx, const uint8_t* valid, const uint8_t* overlap, const double* regr,
+                               int32_t fw, int32_t fh, int32_t a, double std_scaling, float* y_cls, float* y_regr);
+
+/* ---- RoI labelling: rpn.calc_iou (rpn.py:176-296) ----------------------------------------------
+ * rois int64 [n][4] xyxy (feature-map units), gt as above + gt_cls int32 [g] class index.
+ * Per RoI: keep (0/1), cls (class index; bg for hard negatives), box int32 [4] (x,y,w,h),
+ * t fp64 [4] = (sx*tx, sy*ty, sw*tw, sh*th) (zeros unless foreground), iou fp64. */
+int radnet_roi_targets(radnet_ctx* ctx, const int64_t* rois, int32_t n, const double* gt, const int32_t* gt_cls, int32_t g,
+                       int32_t width, int32_t height, int32_t rw, int32_t rh, double rpn_stride, double min_overlap,
+                       double max_overlap, const double* regr_std_host4, int32_t bg_class, uint8_t* keep, int32_t* cls,
+                       int32_t* box, double* t, double* iou);
+/* Build the detector batch for `r` selected RoIs: rois_out fp32 [r][4], y1 [r][nc], y2 [r][8(nc-1)]. */
+int radnet_roi_batch_pack(radnet_ctx* ctx, const int32_t* sel, int32_t r, const int32_t* cls, const int32_t* box,
+                          const double* t, int32_t nc, int32_t bg_class, float* rois_out, float* y1, float* y2);
+
+/* ---- small utilities ---------------------------------------------------------------------------- */
+/* uint8 BGR HWC image -> fp32 NHWC with `cpad` channels (zeros beyond 3), minus the caffe BGR means
+ * (RADNet.py:83-87 / utils.py:468-472 with keras 'caffe' preprocess_input). */
+int radnet_preprocess_bgr(radnet_ctx* ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cpad, float* out);
+int radnet_fill_zero(radnet_ctx* ctx, void* p, uint64_t bytes);
+/* y = x * alpha (n floats); used to average gradients after all-reduce */
+int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha);
+/* out[i] = a[i]*b[i] + c[i]: refreshes the folded epilogue shift (BN scale * conv bias + BN shift,
+ * FixedBatchNormalization.py:59-85) of the trainable head convs after an optimizer step. */
+int radnet_affine_vec(radnet_ctx* ctx, float* out, const float* a, const float* b, const float* c, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADNET_HIP_H */

@@ -1,0 +1,103 @@
+// Context management, error reporting and GEMM-launch timing for libradnet_hip.so.
+#include "radnet_internal.h"
+
+extern "C" int radnet_version(void) { return 100; }
+
+extern "C" int radnet_create(int device, void* hip_stream, radnet_ctx** out) {
+  if (!out) return RADNET_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RADNET_ERR_HIP;   // no GPU: fail loudly
+  if (device < 0 || device >= ndev) return RADNET_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return RADNET_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RADNET_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RADNET_ERR_UNSUPPORTED;   // gfx950-only code objects
+  radnet_ctx* c = new radnet_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  *out = c;
+  return RADNET_OK;
+}
+
+extern "C" void radnet_destroy(radnet_ctx* ctx) {
+  if (!ctx) return;
+  for (int i = 0; i < ctx->n_events_alloc; ++i) {
+    (void)hipEventDestroy(ctx->pend0[i]);
+    (void)hipEventDestroy(ctx->pend1[i]);
+  }
+  delete ctx;
+}
+
+extern "C" const char* radnet_last_error(radnet_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int radnet_sync(radnet_ctx* ctx) {
+  if (!ctx) return RADNET_ERR_ARG;
+  RADNET_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RADNET_OK;
+}
+
+extern "C" int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes) {
+  if (!ctx) return RADNET_ERR_ARG;
+  ctx->ws = ws;
+  ctx->ws_bytes = bytes;
+  return RADNET_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------
+static void resolve_pending(radnet_ctx* ctx) {
+  for (int i = 0; i < ctx->n_pending; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ctx->pend1[i]) == hipSuccess && hipEventElapsedTime(&ms, ctx->pend0[i], ctx->pend1[i]) == hipSuccess) {
+      radnet_timing_slot& s = ctx->slots[ctx->pend_cls[i]];
+      s.ms += ms;
+      s.flops += ctx->pend_flops[i];
+      s.launches += 1;
+    }
+  }
+  ctx->n_pending = 0;
+}
+
+void radnet_timing_begin(radnet_ctx* ctx) {
+  if (!ctx->timing) return;
+  if (ctx->n_pending >= radnet_ctx::kMaxPending) resolve_pending(ctx);
+  int i = ctx->n_pending;
+  if (i >= ctx->n_events_alloc) {
+    (void)hipEventCreate(&ctx->pend0[i]);
+    (void)hipEventCreate(&ctx->pend1[i]);
+    ctx->n_events_alloc = i + 1;
+  }
+  (void)hipEventRecord(ctx->pend0[i], ctx->stream);
+}
+
+void radnet_timing_end(radnet_ctx* ctx, int cls, double flops) {
+  if (!ctx->timing) return;
+  int i = ctx->n_pending;
+  (void)hipEventRecord(ctx->pend1[i], ctx->stream);
+  ctx->pend_cls[i] = cls;
+  ctx->pend_flops[i] = flops;
+  ctx->n_pending = i + 1;
+}
+
+extern "C" int radnet_timing_enable(radnet_ctx* ctx, int enable) {
+  if (!ctx) return RADNET_ERR_ARG;
+  if (!enable) resolve_pending(ctx);
+  ctx->timing = enable;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_timing_reset(radnet_ctx* ctx) {
+  if (!ctx) return RADNET_ERR_ARG;
+  resolve_pending(ctx);
+  for (auto& s : ctx->slots) s = radnet_timing_slot();
+  return RADNET_OK;
+}
+
+extern "C" int radnet_timing_read(radnet_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops) {
+  if (!ctx || cls < 0 || cls > 2) return RADNET_ERR_ARG;
+  resolve_pending(ctx);
+  if (ms) *ms = ctx->slots[cls].ms;
+  if (launches) *launches = ctx->slots[cls].launches;
+  if (flops) *flops = ctx->slots[cls].flops;
+  return RADNET_OK;
+}

@@ -1,0 +1,607 @@
+// Convolution as implicit GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Stands in for keras Conv2D / TimeDistributed(Conv2D) + FixedBatchNormalization + Add + Activation
+// of the reference graph (base_models/resnet50.py:41-147,183-186; rpn.py:41-64;
+// FixedBatchNormalization.py:59-85) and for the TF autodiff gradients of those layers.
+//
+// Design (MI355X-first):
+//   * NHWC activations, weights [K=(kh,kw,c)][N]: the im2col matrix is never materialised; each
+//     workgroup gathers its A tile (BM output pixels x 32 k) straight from the activation tensor with
+//     16-byte loads (4 consecutive channels), zero-filling padding / out-of-range rows.
+//   * 256 threads = 4 wavefronts in a 2x2 arrangement; each wave owns a (BM/2)x(BN/2) block of the
+//     output as 32x32 MFMA tiles kept in accumulator registers for the whole K loop.
+//   * LDS holds both operands reduction-major ([k][m] and [k][n]) so that every MFMA operand
+//     fetch is one conflict-free ds_read_b32 per lane (lanes 0-31 = 32 consecutive rows/cols of
+//     k, lanes 32-63 = k+1).  The A tile is transposed on its way into LDS with a row pitch of
+//     BM+1 words (bank-conflict free for the 4x8 lane pattern of the store, see store_trans).
+//   * global loads of tile t+1 are issued before the MFMA loop of tile t and written to the other
+//     LDS buffer afterwards: one barrier per 32-deep K step.
+//   * epilogue fused: frozen-BN scale/shift (+bias), residual add, ReLU / sigmoid; for dgrad the
+//     residual-path gradient add and the producer's ReLU mask.
+//   * fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak), 16x less than bf16, so LDS and
+//     L2 bandwidth are far from limiting; what matters is filling 256 CUs at batch 1 -- hence the
+//     tile-shape selection and split-K in the launchers below.
+#include "radnet_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;          // reduction depth per LDS tile
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+  const float* x;        // gathered activation tensor (NHWC)
+  const float* w;        // B operand base
+  float* y;              // output [M][ldy]
+  const float* scale;    // epilogue per-column scale
+  const float* shift;    // epilogue per-column shift
+  const float* addend;   // epilogue addend [M][ld_add]
+  const float* mask;     // epilogue mask   [M][ld_mask] (zero where <= 0)
+  const float* in_scale; // per-gathered-channel factor (C entries) or null
+  float* partial;        // split-K partial sums [split][M][N] (null = direct epilogue)
+  int H, W, C;           // gathered tensor geometry
+  int OH, OW;            // output spatial geometry
+  int KW, npos;          // kernel width, kh*kw
+  int stride, pad_t, pad_l;
+  int M, N, K;           // GEMM sizes, K = npos*C
+  int ldw, ldy, ld_add, ld_mask;
+  int act, act_cols;
+  int flip;              // dgrad: kernel position flipped (npos-1-pos)
+  int cin_fwd;           // dgrad B addressing: forward input channels (= N here)
+  int kt_per_split;      // K tiles per split
+  unsigned long long magic_ohow, magic_ow;
+  int OHOW;
+};
+
+__device__ __forceinline__ int div_magic(int m, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
+}
+
+// ---- operand staging -----------------------------------------------------------------------------
+// transposed store: thread holds 4 consecutive-k values of one row; LDS layout [k][pitch] with
+// pitch == 1 (mod 32).  For a 32-lane half, rows t/8 (4 values) x kc=t%8 (8 values) hit bank
+// (4*kc + j + row) % 32: 32 distinct banks -> conflict free.
+__device__ __forceinline__ void store_trans(float* s, int pitch, int row, int kc, float4 v) {
+  float* p = s + (kc * 4) * pitch + row;
+  p[0] = v.x;
+  p[pitch] = v.y;
+  p[2 * pitch] = v.z;
+  p[3 * pitch] = v.w;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int pitchA, int pitchB, int a_off, int b_off,
+                                          f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int s = 0; s < BK / 2; ++s) {
+    float a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = sA[(2 * s) * pitchA + a_off + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = sB[(2 * s) * pitchB + b_off + j * 32];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// ---- forward / dgrad kernel -------------------------------------------------------------------------
+// BMODE 0: B is [K][ldw] row-major (forward).  BMODE 1: B element (k=(pos,co), n=ci) lives at
+//          w[((flip(pos)*cin_fwd + ci) * ldw) + co]  (dgrad: same weight buffer, read transposed).
+// SMALLC : C == 4 (stem with the image padded to 4 channels): one 4-float chunk per kernel position.
+template <int BM, int BN, int BMODE, bool SMALLC>
+__global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
+  constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave in each direction
+  constexpr int PA = BM + 1;                    // A pitch (transposed store)
+  constexpr int PB = (BMODE == 0) ? (BN + 4) : (BN + 1);
+  constexpr int A_ITERS = BM / 32;              // float4 chunks per thread (A)
+  constexpr int B_ITERS = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (PA + PB)];
+  float* sA0 = lds;
+  float* sB0 = lds + 2 * BK * PA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int split = blockIdx.z;
+
+  // ---- per-thread A rows: decode m -> (image, oh, ow) once
+  const int a_kc = tid & 7;
+  int a_pix[A_ITERS], a_ih0[A_ITERS], a_iw0[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    if (m < g.M) {
+      int img = div_magic(m, g.magic_ohow);
+      int rem = m - img * g.OHOW;
+      int oh = div_magic(rem, g.magic_ow);
+      int ow = rem - oh * g.OW;
+      a_pix[i] = img * g.H * g.W;
+      a_ih0[i] = oh * g.stride - g.pad_t;
+      a_iw0[i] = ow * g.stride - g.pad_l;
+    } else {
+      a_pix[i] = -1;
+      a_ih0[i] = 0;
+      a_iw0[i] = 0;
+    }
+  }
+
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int kt_begin = split * g.kt_per_split;
+  int kt_end = kt_begin + g.kt_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+
+  // running position of the current K tile: (pos, ci0) with k0 = pos*C + ci0
+  int pos = 0, ci0 = 0;
+  if (!SMALLC) {
+    int k0 = kt_begin * BK;
+    pos = k0 / g.C;
+    ci0 = k0 - pos * g.C;
+  }
+
+  float4 ra[A_ITERS], rb[B_ITERS];
+
+  auto load_tile = [&](int kt) {
+    // ---------------- A: implicit im2col gather
+    if (SMALLC) {
+      int p = kt * 8 + a_kc;                 // kernel position of this thread's chunk
+      int kh = p / g.KW, kw = p - kh * g.KW;
+      bool pv = p < g.npos;
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        bool ok = pv && a_pix[i] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(g.x + (size_t)(a_pix[i] + ih * g.W + iw) * 4) : make_float4(0, 0, 0, 0);
+      }
+    } else {
+      int kh = pos / g.KW, kw = pos - kh * g.KW;
+      int ci = ci0 + a_kc * 4;
+      bool kv = (pos * g.C + ci) < g.K;
+      float4 sc = make_float4(1, 1, 1, 1);
+      if (g.in_scale != nullptr && kv) sc = *reinterpret_cast<const float4*>(g.in_scale + ci);
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        bool ok = kv && a_pix[i] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (ok) {
+          v = *reinterpret_cast<const float4*>(g.x + (size_t)(a_pix[i] + ih * g.W + iw) * g.C + ci);
+          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+        }
+        ra[i] = v;
+      }
+    }
+    // ---------------- B
+    if (BMODE == 0) {
+      constexpr int CPR = BN / 4;            // float4 chunks per k row
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        int c = tid + NTHREADS * i;
+        int kr = c / CPR, n4 = c - kr * CPR;
+        int k = kt * BK + kr, n = n0 + n4 * 4;
+        bool ok = k < g.K && n < g.N;        // N is a multiple of 4 (launcher checks ldw % 4 == 0)
+        rb[i] = ok ? *reinterpret_cast<const float4*>(g.w + (size_t)k * g.ldw + n) : make_float4(0, 0, 0, 0);
+      }
+    } else {
+      int fpos = g.flip ? (g.npos - 1 - pos) : pos;
+      int co = ci0 + a_kc * 4;              // gathered channel == forward output channel
+      bool kv = (pos * g.C + co) < g.K;
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
+        bool ok = kv && n < g.N;
+        rb[i] = ok ? *reinterpret_cast<const float4*>(g.w + ((size_t)fpos * g.cin_fwd + n) * g.ldw + co) : make_float4(0, 0, 0, 0);
+      }
+    }
+    if (!SMALLC) {
+      ci0 += BK;
+      if (ci0 >= g.C) { ci0 = 0; ++pos; }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* sA = sA0 + buf * BK * PA;
+    float* sB = sB0 + buf * BK * PB;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) store_trans(sA, PA, (tid >> 3) + 32 * i, a_kc, ra[i]);
+    if (BMODE == 0) {
+      constexpr int CPR = BN / 4;
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        int c = tid + NTHREADS * i;
+        int kr = c / CPR, n4 = c - kr * CPR;
+        *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) store_trans(sB, PB, (tid >> 3) + 32 * i, a_kc, rb[i]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+    __syncthreads();
+    const int a_off = hi * PA + wm * (BM / 2) + l31;
+    const int b_off = hi * PB + wn * (BN / 2) + l31;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if (more) load_tile(kt + 1);
+      mfma_tile<TM, TN>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, acc);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: accumulator register r of a 32x32 tile = row (r&3)+8*(r>>2)+4*hi, column lane&31
+  const bool direct = g.partial == nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+    const bool nv = n < g.N;
+    float sc = 1.f, sh = 0.f;
+    if (direct && nv) {
+      if (g.scale) sc = g.scale[n];
+      if (g.shift) sh = g.shift[n];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (nv && m < g.M) {
+          float v = acc[i][j][r];
+          if (direct) {
+            v = v * sc + sh;
+            if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+            if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
+            g.y[(size_t)m * g.ldy + n] = v;
+          } else {
+            g.partial[((size_t)split * g.M + m) * g.N + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- split-K reduction + epilogue ------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(GemmArgs g, int splits) {
+  const int n4 = g.N >> 2;
+  const long long total = (long long)g.M * n4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (long long)m * n4) * 4;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < splits; ++k) {
+      float4 p = *reinterpret_cast<const float4*>(g.partial + ((size_t)k * g.M + m) * g.N + n);
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float t = v[q];
+      if (g.scale) t *= g.scale[n + q];
+      if (g.shift) t += g.shift[n + q];
+      if (g.addend) t += g.addend[(size_t)m * g.ld_add + n + q];
+      if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n + q] > 0.f)) t = 0.f;
+      if (g.act == 1) t = fmaxf(t, 0.f);
+      else if (g.act == 2 && n + q < g.act_cols) t = 1.f / (1.f + __expf(-t));
+      g.y[(size_t)m * g.ldy + n + q] = t;
+    }
+  }
+}
+
+// ---- wgrad kernel -----------------------------------------------------------------------------------
+// dW[k][n] (+)= sum_m im2col(x)[m][k] * (dy[m][n] * gscale[n]).  Output tile BMK (k) x BN (n); the
+// reduction runs over output pixels m in steps of 32, optionally split across blockIdx.z (atomics).
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  const float* gscale;
+  float* dw;
+  int H, W, C, OH, OW, KW, stride, pad_t, pad_l;
+  int M, N, K;
+  int ld_dy, ldw;
+  int mt_per_split;
+  int atomic;
+  unsigned long long magic_ohow, magic_ow;
+  int OHOW;
+};
+
+template <int BMK, int BN>
+__global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
+  constexpr int TM = BMK / 64, TN = BN / 64;
+  constexpr int PA = BMK + 4, PB = BN + 4;
+  constexpr int A_ITERS = BMK / 32, B_ITERS = BN / 32;
+  constexpr int CPRA = BMK / 4, CPRB = BN / 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (PA + PB)];
+  float* sA0 = lds;
+  float* sB0 = lds + 2 * BK * PA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k0 = blockIdx.x * BMK, n0 = blockIdx.y * BN;
+
+  // this block's k range lies inside one kernel position when C % BMK == 0 (launcher guarantees)
+  const int pos = k0 / g.C;
+  const int cbase = k0 - pos * g.C;
+  const int kh = pos / g.KW, kw = pos - kh * g.KW;
+
+  const int a_k4 = tid % CPRA, a_mr = tid / CPRA;      // A_ITERS rows: a_mr + (NTHREADS/CPRA)*i
+  const int b_n4 = tid % CPRB, b_mr = tid / CPRB;
+  const bool a_kv = (k0 + a_k4 * 4) < g.K;
+  const bool b_nv = (n0 + b_n4 * 4) < g.N;
+  float4 gs = make_float4(1, 1, 1, 1);
+  if (g.gscale != nullptr && b_nv) gs = *reinterpret_cast<const float4*>(g.gscale + n0 + b_n4 * 4);
+
+  const int nmt = (g.M + BK - 1) / BK;
+  const int mt_begin = blockIdx.z * g.mt_per_split;
+  int mt_end = mt_begin + g.mt_per_split;
+  if (mt_end > nmt) mt_end = nmt;
+
+  float4 ra[A_ITERS], rb[B_ITERS];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (m < g.M && a_kv) {
+        int img = div_magic(m, g.magic_ohow);
+        int rem = m - img * g.OHOW;
+        int oh = div_magic(rem, g.magic_ow);
+        int ow = rem - oh * g.OW;
+        int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+          v = *reinterpret_cast<const float4*>(g.x + ((size_t)(img * g.H + ih) * g.W + iw) * g.C + cbase + a_k4 * 4);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      int m = mt * BK + b_mr + (NTHREADS / CPRB) * i;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (m < g.M && b_nv) {
+        v = *reinterpret_cast<const float4*>(g.dy + (size_t)m * g.ld_dy + n0 + b_n4 * 4);
+        v.x *= gs.x; v.y *= gs.y; v.z *= gs.z; v.w *= gs.w;
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* sA = sA0 + buf * BK * PA;
+    float* sB = sB0 + buf * BK * PB;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i)
+      *reinterpret_cast<float4*>(sA + (a_mr + (NTHREADS / CPRA) * i) * PA + a_k4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      *reinterpret_cast<float4*>(sB + (b_mr + (NTHREADS / CPRB) * i) * PB + b_n4 * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (mt_begin < mt_end) {
+    load_tile(mt_begin);
+    store_tile(0);
+    __syncthreads();
+    const int a_off = hi * PA + wm * (BMK / 2) + l31;
+    const int b_off = hi * PB + wn * (BN / 2) + l31;
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+      const int buf = (mt - mt_begin) & 1;
+      const bool more = mt + 1 < mt_end;
+      if (more) load_tile(mt + 1);
+      mfma_tile<TM, TN>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, acc);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + wm * (BMK / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (n < g.N && k < g.K) {
+          float* p = g.dw + (size_t)k * g.ldw + n;
+          if (g.atomic) atomicAdd(p, acc[i][j][r]);
+          else *p = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------------
+constexpr int kNumCU = 256;
+
+struct TileChoice {
+  int bm, bn, splits;
+};
+
+// Pick the output tile and split-K factor.  Cost model (CU-time in MAC units, 128 MAC/clk/CU):
+//   rounds = ceil(units / 256 CUs); unit = tile MACs / tile efficiency + fixed prologue/epilogue cost;
+//   split-K adds the partial-sum write + reduce pass and one more launch.
+// ctx->tune (radnet_conv_autotune) replaces this guess with measured choices per problem shape.
+TileChoice choose_tiles(int M, int N, int K, bool allow_split) {
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  const double eff[4] = {1.0, 0.95, 0.95, 0.85};
+  const double kMacPerUs = 128.0 * 2100.0;          // per CU
+  const double kFixed = 2.0 * kMacPerUs;            // ~2 us per work unit
+  TileChoice best{64, 64, 1};
+  double best_cost = 1e30;
+  const int nk = radnet_cdiv(K, BK);
+  for (int c = 0; c < 4; ++c) {
+    const int bm = cand[c][0], bn = cand[c][1];
+    if (bn > 64 && N <= 64) continue;
+    if (bm > 64 && M <= 64) continue;
+    const long long tiles = (long long)radnet_cdiv(M, bm) * radnet_cdiv(N, bn);
+    for (int s = 1; s <= (allow_split ? 16 : 1); ++s) {
+      if (s > 1 && nk / s < 6) break;
+      const int kt = radnet_cdiv(nk, s);
+      if (s > 1 && radnet_cdiv(nk, kt) != s) continue;   // would leave an empty split
+      const long long units = tiles * s;
+      const double rounds = (double)((units + kNumCU - 1) / kNumCU);
+      double cost = rounds * ((double)bm * bn * kt * BK / eff[c] + kFixed);
+      if (s > 1) cost += (2.0 + 8.0 * (double)M * N * s / 3.0e6) * kMacPerUs;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = TileChoice{bm, bn, s};
+      }
+    }
+  }
+  return best;
+}
+
+template <int BMODE, bool SMALLC>
+void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc) {
+  dim3 block(NTHREADS);
+  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), tc.splits);
+  if (tc.bm == 128 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, BMODE, SMALLC>), grid, block, 0, st, g);
+  else if (tc.bm == 128 && tc.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, BMODE, SMALLC>), grid, block, 0, st, g);
+  else if (tc.bm == 64 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<64, 128, BMODE, SMALLC>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, BMODE, SMALLC>), grid, block, 0, st, g);
+}
+
+int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+  if (g.M >= (1 << 20) || g.OHOW >= (1 << 20)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: M=%d exceeds 2^20 rows", g.M);
+  if ((g.ldw & 3) || (g.N & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: N=%d and ldw=%d must be multiples of 4", g.N, g.ldw);
+  if (((uintptr_t)g.x & 15) || ((uintptr_t)g.w & 15)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: x / w must be 16-byte aligned");
+  if (!smallc && (g.C % BK) != 0) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: channels %d not a multiple of %d (pad, or use c=4)", g.C, BK);
+  g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
+  g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  TileChoice tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
+  if (tc.splits > 1) {
+    const uint64_t need = (uint64_t)tc.splits * g.M * g.N * sizeof(float);
+    if (need > ctx->ws_bytes) tc.splits = 1;
+  }
+  const int nk = radnet_cdiv(g.K, BK);
+  g.kt_per_split = radnet_cdiv(nk, tc.splits);
+  g.partial = tc.splits > 1 ? (float*)ctx->ws : nullptr;
+  radnet_timing_begin(ctx);
+  if (bmode == 0) {
+    if (smallc) launch_igemm<0, true>(ctx->stream, g, tc);
+    else launch_igemm<0, false>(ctx->stream, g, tc);
+  } else {
+    launch_igemm<1, false>(ctx->stream, g, tc);
+  }
+  RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
+  if (tc.splits > 1) {
+    const long long total = (long long)g.M * (g.N >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g, tc.splits);
+    RADNET_CHECK_LAUNCH(ctx, "splitk_epilogue");
+  }
+  radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K);
+  return RADNET_OK;
+}
+
+}  // namespace
+
+extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  if (!ctx || !d) return RADNET_ERR_ARG;
+  if (!d->x || !d->w || !d->y) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_fwd: null tensor");
+  GemmArgs g{};
+  g.x = d->x; g.w = d->w; g.y = d->y;
+  g.scale = d->scale; g.shift = d->shift; g.addend = d->addend; g.mask = nullptr; g.in_scale = nullptr;
+  g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow;
+  g.KW = d->kw; g.npos = d->kh * d->kw; g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
+  g.M = d->nb * d->oh * d->ow; g.N = d->n; g.K = g.npos * d->c;
+  g.ldw = d->ldw; g.ldy = d->ldy; g.ld_add = d->ld_add; g.ld_mask = 0;
+  g.act = d->act; g.act_cols = d->act_cols; g.flip = 0; g.cin_fwd = 0;
+  g.OHOW = d->oh * d->ow;
+  // geometry sanity: every output pixel's window must be addressable by the gather's bounds checks
+  if ((d->oh - 1) * d->stride - d->pad_t >= d->h || (d->ow - 1) * d->stride - d->pad_l >= d->w_)
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_fwd: output %dx%d inconsistent with input %dx%d", d->oh, d->ow, d->h, d->w_);
+  return run_igemm(ctx, g, 0, d->c == 4, 0);
+}
+
+extern "C" int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  if (!ctx || !d) return RADNET_ERR_ARG;
+  if (!d->dy || !d->w || !d->dx) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_dgrad: null tensor");
+  if (d->stride != 1) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_dgrad: stride %d (only 1)", d->stride);
+  if (d->ld_dy != d->n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_dgrad: dy must be dense (ld_dy == n)");
+  GemmArgs g{};
+  g.x = d->dy; g.w = d->w; g.y = d->dx;
+  g.scale = nullptr; g.shift = nullptr; g.addend = d->dx_add; g.mask = d->dx_mask; g.in_scale = d->gscale;
+  // gather from dy (nb, oh, ow, n) with the kernel flipped; output pixels = forward input pixels
+  g.H = d->oh; g.W = d->ow; g.C = d->n; g.OH = d->h; g.OW = d->w_;
+  g.KW = d->kw; g.npos = d->kh * d->kw; g.stride = 1; g.pad_t = d->kh - 1 - d->pad_t; g.pad_l = d->kw - 1 - d->pad_l;
+  g.M = d->nb * d->h * d->w_; g.N = d->c; g.K = g.npos * d->n;
+  g.ldw = d->ldw; g.ldy = d->ld_dx; g.ld_add = d->ld_dx_add; g.ld_mask = d->ld_dx_mask;
+  g.act = 0; g.act_cols = 0; g.flip = 1; g.cin_fwd = d->c;
+  g.OHOW = d->h * d->w_;
+  if (d->n % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_dgrad: n must be a multiple of 4");
+  return run_igemm(ctx, g, 1, false, 1);
+}
+
+extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  if (!ctx || !d) return RADNET_ERR_ARG;
+  if (!d->x || !d->dy || !d->dw) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: null tensor");
+  WgradArgs g{};
+  g.x = d->x; g.dy = d->dy; g.gscale = d->gscale; g.dw = d->dw;
+  g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow; g.KW = d->kw;
+  g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
+  g.M = d->nb * d->oh * d->ow; g.N = d->n; g.K = d->kh * d->kw * d->c;
+  g.ld_dy = d->ld_dy; g.ldw = d->ldw;
+  g.OHOW = d->oh * d->ow;
+  if (g.M >= (1 << 20)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: M=%d exceeds 2^20", g.M);
+  if ((g.N & 3) || (g.ld_dy & 3) || (g.ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: n, ld_dy, ldw must be multiples of 4");
+  g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
+  g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  int bmk = (d->c % 128 == 0) ? 128 : 64;
+  if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
+  int bn = g.N > 64 ? 128 : 64;
+  long long tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
+  if (tiles < kNumCU && bmk == 128 && bn == 128) {
+    // more, smaller tiles first (no atomics needed)
+    bn = 64;
+    tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
+  }
+  const int nmt = radnet_cdiv(g.M, BK);
+  int splits = 1;
+  while (tiles * splits < 2 * kNumCU && nmt / (splits * 2) >= 4 && splits < 16) splits *= 2;
+  g.mt_per_split = radnet_cdiv(nmt, splits);
+  g.atomic = (splits > 1 || d->dw_accumulate) ? 1 : 0;
+  if (splits > 1 && !d->dw_accumulate) {
+    // atomics need a zeroed destination
+    RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
+  }
+  dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits), block(NTHREADS);
+  radnet_timing_begin(ctx);
+  if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
+  else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
+  else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, ctx->stream, g);
+  RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
+  radnet_timing_end(ctx, 2, 2.0 * g.M * g.N * g.K);
+  return RADNET_OK;
+}

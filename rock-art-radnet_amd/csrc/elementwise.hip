@@ -1,0 +1,590 @@
+// HBM-bound and small kernels of the Faster R-CNN hot path: pooling, RoI crop-resize, classifier
+// dense heads, losses (forward value + gradient in one pass), bias-gradient column sums, Adam.
+// Each stands in for a TensorFlow op the reference graph invokes implicitly; citations inline.
+#include "radnet_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- MaxPooling2D k x k / stride s, 'valid' (resnet50.py:188; VGG16 block pools) ------------------
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int nb, int h, int w,
+                                                      int c4, int oh, int ow, int k, int s) {
+  const long long total = (long long)nb * oh * ow * c4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int cc = (int)(idx % c4);
+    long long p = idx / c4;
+    int ox = (int)(p % ow);
+    p /= ow;
+    int oy = (int)(p % oh);
+    int b = (int)(p / oh);
+    const float4* src = reinterpret_cast<const float4*>(x) + ((long long)(b * h + oy * s) * w + ox * s) * c4 + cc;
+    float4 m = src[0];
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) {
+        float4 v = src[((long long)i * w + j) * c4];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    reinterpret_cast<float4*>(y)[idx] = m;
+  }
+}
+
+// ---- RoiPoolingConv.call (RoiPoolingConv.py:48-88): crop + TF1 legacy bilinear resize ---------------
+struct RoiGeom {
+  int x0, y0, cw, ch;
+};
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, int H, int W) {
+  int x = (int)roi[0], y = (int)roi[1], w = (int)roi[2], h = (int)roi[3];   // K.cast(..., 'int32'): truncation
+  int y0 = min(max(y, 0), H), y1 = min(max(y + h, 0), H);                   // slice clamping
+  int x0 = min(max(x, 0), W), x1 = min(max(x + w, 0), W);
+  return RoiGeom{x0, y0, x1 - x0, y1 - y0};
+}
+
+// one workgroup per output pixel (roi, oy, ox); threads stride over channel quads: every global access
+// is a run of consecutive 16-byte words (1 KiB per wave instruction), the 4 taps come from L2/L1.
+__global__ void __launch_bounds__(256) roi_resize_fwd_kernel(const float* __restrict__ fmap, int H, int W, int c4,
+                                                             const float* __restrict__ rois, int ps, float* __restrict__ y) {
+  const int o = blockIdx.x;
+  const int ox = o % ps, oy = (o / ps) % ps, r = o / (ps * ps);
+  const RoiGeom g = roi_geom(rois + 4 * r, H, W);
+  float4* dst = reinterpret_cast<float4*>(y) + (long long)o * c4;
+  if (g.cw <= 0 || g.ch <= 0) {
+    for (int c = threadIdx.x; c < c4; c += blockDim.x) dst[c] = make_float4(0, 0, 0, 0);
+    return;
+  }
+  const float hs = (float)g.ch / (float)ps, ws = (float)g.cw / (float)ps;
+  const float sy = (float)oy * hs, sx = (float)ox * ws;
+  const int ylo = (int)floorf(sy), xlo = (int)floorf(sx);
+  const int yhi = min(ylo + 1, g.ch - 1), xhi = min(xlo + 1, g.cw - 1);
+  const float ly = sy - (float)ylo, lx = sx - (float)xlo;
+  const float4* f = reinterpret_cast<const float4*>(fmap);
+  const float4* tl = f + ((long long)(g.y0 + ylo) * W + g.x0 + xlo) * c4;
+  const float4* tr = f + ((long long)(g.y0 + ylo) * W + g.x0 + xhi) * c4;
+  const float4* bl = f + ((long long)(g.y0 + yhi) * W + g.x0 + xlo) * c4;
+  const float4* br = f + ((long long)(g.y0 + yhi) * W + g.x0 + xhi) * c4;
+  for (int c = threadIdx.x; c < c4; c += blockDim.x) {
+    float4 a = tl[c], b = tr[c], d = bl[c], e = br[c], out;
+#define LERP2(q)                                         \
+  {                                                      \
+    float top = a.q + (b.q - a.q) * lx;                  \
+    float bot = d.q + (e.q - d.q) * lx;                  \
+    out.q = top + (bot - top) * ly;                      \
+  }
+    LERP2(x) LERP2(y) LERP2(z) LERP2(w)
+#undef LERP2
+    dst[c] = out;
+  }
+}
+
+__global__ void __launch_bounds__(256) roi_resize_bwd_kernel(const float* __restrict__ dy, int H, int W, int C,
+                                                             const float* __restrict__ rois, int ps, float* __restrict__ dfmap) {
+  const int o = blockIdx.x;
+  const int ox = o % ps, oy = (o / ps) % ps, r = o / (ps * ps);
+  const RoiGeom g = roi_geom(rois + 4 * r, H, W);
+  if (g.cw <= 0 || g.ch <= 0) return;
+  const float hs = (float)g.ch / (float)ps, ws = (float)g.cw / (float)ps;
+  const float sy = (float)oy * hs, sx = (float)ox * ws;
+  const int ylo = (int)floorf(sy), xlo = (int)floorf(sx);
+  const int yhi = min(ylo + 1, g.ch - 1), xhi = min(xlo + 1, g.cw - 1);
+  const float ly = sy - (float)ylo, lx = sx - (float)xlo;
+  float* tl = dfmap + ((long long)(g.y0 + ylo) * W + g.x0 + xlo) * C;
+  float* tr = dfmap + ((long long)(g.y0 + ylo) * W + g.x0 + xhi) * C;
+  float* bl = dfmap + ((long long)(g.y0 + yhi) * W + g.x0 + xlo) * C;
+  float* br = dfmap + ((long long)(g.y0 + yhi) * W + g.x0 + xhi) * C;
+  const float* src = dy + (long long)o * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = src[c];
+    atomicAdd(tl + c, v * (1.f - ly) * (1.f - lx));
+    atomicAdd(tr + c, v * (1.f - ly) * lx);
+    atomicAdd(bl + c, v * ly * (1.f - lx));
+    atomicAdd(br + c, v * ly * lx);
+  }
+}
+
+// ---- AveragePooling2D((7,7)) + Flatten over the RoI axis (resnet50.py:260-261) ----------------------
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, int r, int hw, int c4, float* __restrict__ y) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= r * c4) return;
+  const int rr = idx / c4, cc = idx - rr * c4;
+  const float4* src = reinterpret_cast<const float4*>(x) + (long long)rr * hw * c4 + cc;
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int p = 0; p < hw; ++p) {
+    float4 v = src[(long long)p * c4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = (float)hw;
+  reinterpret_cast<float4*>(y)[idx] = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+}
+
+__global__ void __launch_bounds__(256) avgpool_bwd_relu_kernel(const float* __restrict__ dfeat, const float* __restrict__ yact,
+                                                               int r, int hw, int c4, float* __restrict__ dx) {
+  const long long total = (long long)r * hw * c4;
+  const float inv = (float)hw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int cc = (int)(idx % c4);
+    int rr = (int)(idx / ((long long)hw * c4));
+    float4 g = reinterpret_cast<const float4*>(dfeat)[(long long)rr * c4 + cc];
+    float4 a = reinterpret_cast<const float4*>(yact)[idx];
+    float4 o;
+    o.x = a.x > 0.f ? g.x / inv : 0.f;
+    o.y = a.y > 0.f ? g.y / inv : 0.f;
+    o.z = a.z > 0.f ? g.z / inv : 0.f;
+    o.w = a.w > 0.f ? g.w / inv : 0.f;
+    reinterpret_cast<float4*>(dx)[idx] = o;
+  }
+}
+
+// ---- classifier dense heads (resnet50.py:263-279): one workgroup per RoI --------------------------------
+template <int NP>
+__global__ void __launch_bounds__(256) dense_heads_fwd_kernel(const float* __restrict__ feat, int k, const float* __restrict__ w,
+                                                              const float* __restrict__ b, int nc, int nreg,
+                                                              float* __restrict__ out_cls, float* __restrict__ out_regr) {
+  __shared__ float red[4][NP];
+  __shared__ float z[NP];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[NP];
+#pragma unroll
+  for (int n = 0; n < NP; ++n) acc[n] = 0.f;
+  const float* f = feat + (long long)r * k;
+  for (int kk = tid; kk < k; kk += 256) {
+    const float xv = f[kk];
+    const float4* wr = reinterpret_cast<const float4*>(w + (long long)kk * NP);
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q) {
+      float4 v = wr[q];
+      acc[4 * q + 0] += xv * v.x; acc[4 * q + 1] += xv * v.y; acc[4 * q + 2] += xv * v.z; acc[4 * q + 3] += xv * v.w;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NP; ++n) {
+    float s = wave_sum(acc[n]);
+    if (lane == 0) red[wave][n] = s;
+  }
+  __syncthreads();
+  const int nout = nc + nreg;
+  if (tid < nout) z[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + b[tid];
+  __syncthreads();
+  if (tid < nout) {
+    if (tid < nc) {
+      float mx = z[0];
+      for (int i = 1; i < nc; ++i) mx = fmaxf(mx, z[i]);
+      float s = 0.f;
+      for (int i = 0; i < nc; ++i) s += expf(z[i] - mx);
+      out_cls[(long long)r * nc + tid] = expf(z[tid] - mx) / s;
+    } else {
+      out_regr[(long long)r * nreg + (tid - nc)] = z[tid];
+    }
+  }
+}
+
+// dw[k][n] = sum_r feat[r][k] dz[r][n];  dfeat[r][k] = sum_n dz[r][n] w[k][n];  db[n] = sum_r dz[r][n]
+__global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dz, int r, int k,
+                                                              const float* __restrict__ w, int np, int nout, float* __restrict__ dw,
+                                                              float* __restrict__ db, float* __restrict__ dfeat) {
+  extern __shared__ float sdz[];            // [r][np]
+  for (int i = threadIdx.x; i < r * np; i += blockDim.x) {
+    int rr = i / np, n = i - rr * np;
+    sdz[i] = n < nout ? dz[(long long)rr * nout + n] : 0.f;
+  }
+  __syncthreads();
+  const int kk = blockIdx.x * 8 + (threadIdx.x >> 5);      // 8 k rows per block, 32 threads per row
+  const int t = threadIdx.x & 31;
+  if (kk < k) {
+    for (int n = t; n < np; n += 32) {
+      float s = 0.f;
+      for (int rr = 0; rr < r; ++rr) s += feat[(long long)rr * k + kk] * sdz[rr * np + n];
+      dw[(long long)kk * np + n] = n < nout ? s : 0.f;
+    }
+    for (int rr = t; rr < r; rr += 32) {
+      float s = 0.f;
+      const float* wr = w + (long long)kk * np;
+      for (int n = 0; n < nout; ++n) s += sdz[rr * np + n] * wr[n];
+      dfeat[(long long)rr * k + kk] = s;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < np) {
+    float s = 0.f;
+    for (int rr = 0; rr < r; ++rr) s += sdz[rr * np + threadIdx.x];
+    db[threadIdx.x] = threadIdx.x < nout ? s : 0.f;
+  }
+}
+
+// ---- column sums (bias gradients) ----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int m, int n, int ld, const float* __restrict__ gscale,
+                                                     float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(m, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < n)
+    for (int rr = r0 + ty; rr < r1; rr += 4) s += g[(long long)rr * ld + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < n) {
+    float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (gscale) v *= gscale[col];
+    atomicAdd(out + col, v);
+  }
+}
+
+// ---- keras.optimizers.Adam (Keras 2 update rule) over a flat arena ------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps,
+                                                   float gs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(q)                                         \
+  {                                                      \
+    float gq = gg.q * gs;                                \
+    mm.q = b1 * mm.q + (1.f - b1) * gq;                  \
+    vv.q = b2 * vv.q + (1.f - b2) * gq * gq;             \
+    pp.q = pp.q - lr_t * mm.q / (sqrtf(vv.q) + eps);     \
+  }
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// ---- RPN losses (losses.py:16-66) ------------------------------------------------------------------------------
+// scratch (double): [0] sum valid, [1] sum valid*ce, [2] sum mask, [3] sum mask*smoothL1
+__device__ __forceinline__ float bce_swapped_logit(float t) {
+  // Keras-2 K.binary_crossentropy(target=y_pred, output=y_true): logit of the clipped *label*
+  const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+  float o = fminf(fmaxf(t, lo), hi);
+  return logf(o / (1.0f - o));
+}
+
+__global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,
+                                                            const float* __restrict__ yregr, int m, int a, int bce_mode,
+                                                            double* __restrict__ scratch) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  const long long total = (long long)m * 5 * a;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / (5 * a)), col = (int)(idx - (long long)row * 5 * a);
+    const float p = pred[(long long)row * ld_pred + col];
+    if (col < a) {
+      const float valid = ycls[(long long)row * 2 * a + col], t = ycls[(long long)row * 2 * a + a + col];
+      float ce;
+      if (bce_mode == 0) {
+        const float l = bce_swapped_logit(t);
+        ce = fmaxf(l, 0.f) - l * p + log1pf(expf(-fabsf(l)));
+      } else {
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);
+        const float z = logf(pc / (1.0f - pc));
+        ce = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
+      }
+      s0 += valid;
+      s1 += valid * ce;
+    } else {
+      const int j = col - a;
+      const float mask = yregr[(long long)row * 8 * a + j], tgt = yregr[(long long)row * 8 * a + 4 * a + j];
+      const float x = tgt - p, ax = fabsf(x);
+      const float sl = ax <= 1.0f ? 0.5f * x * x : ax - 0.5f;
+      s2 += mask;
+      s3 += mask * sl;
+    }
+  }
+  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(scratch + 0, s0); atomicAdd(scratch + 1, s1); atomicAdd(scratch + 2, s2); atomicAdd(scratch + 3, s3);
+  }
+}
+
+__global__ void __launch_bounds__(256) rpn_loss_grad_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,
+                                                            const float* __restrict__ yregr, int m, int a, int bce_mode,
+                                                            const double* __restrict__ scratch, float* __restrict__ dz, int ld_dz,
+                                                            float* __restrict__ losses) {
+  const float den_c = (float)(1e-4 * (double)m * a + scratch[0]);
+  const float den_r = (float)(1e-4 * (double)m * 4 * a + scratch[2]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    losses[0] = (float)(scratch[1] / (double)den_c);
+    losses[1] = (float)(scratch[3] / (double)den_r);
+  }
+  const long long total = (long long)m * ld_dz;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / ld_dz), col = (int)(idx - (long long)row * ld_dz);
+    float out = 0.f;
+    if (col < a) {
+      const float p = pred[(long long)row * ld_pred + col];
+      const float valid = ycls[(long long)row * 2 * a + col], t = ycls[(long long)row * 2 * a + a + col];
+      float dce;
+      if (bce_mode == 0) {
+        dce = -bce_swapped_logit(t);
+      } else {
+        const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+        const float pc = fminf(fmaxf(p, lo), hi);
+        dce = (p >= lo && p <= hi) ? (pc - t) / (pc * (1.0f - pc)) : 0.f;
+      }
+      out = valid * dce / den_c * p * (1.0f - p);          // sigmoid' folded in
+    } else if (col < 5 * a) {
+      const int j = col - a;
+      const float p = pred[(long long)row * ld_pred + col];
+      const float mask = yregr[(long long)row * 8 * a + j], tgt = yregr[(long long)row * 8 * a + 4 * a + j];
+      const float x = tgt - p, ax = fabsf(x);
+      const float d = ax <= 1.0f ? x : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+      out = -(mask * d) / den_r;
+    }
+    dz[idx] = out;
+  }
+}
+
+// ---- detector losses (losses.py:69-95), single workgroup ---------------------------------------------------------
+__global__ void __launch_bounds__(256) det_loss_kernel(const float* __restrict__ pcls, const float* __restrict__ pregr,
+                                                       const float* __restrict__ y1, const float* __restrict__ y2, int r, int nc,
+                                                       int nreg, float* __restrict__ dz, float* __restrict__ losses) {
+  __shared__ double red[4][4];
+  __shared__ float s_den;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+  double ce_sum = 0, acc_sum = 0, mask_sum = 0, sl_sum = 0;
+  for (int rr = tid; rr < r; rr += blockDim.x) {
+    const float* q = pcls + (long long)rr * nc;
+    const float* t = y1 + (long long)rr * nc;
+    float S = 0.f;
+    for (int i = 0; i < nc; ++i) S += q[i];
+    float ce = 0.f;
+    int am_t = 0, am_q = 0;
+    for (int i = 0; i < nc; ++i) {
+      float oc = fminf(fmaxf(q[i] / S, lo), hi);
+      ce -= t[i] * logf(oc);
+      if (t[i] > t[am_t]) am_t = i;
+      if (q[i] > q[am_q]) am_q = i;
+    }
+    ce_sum += ce;
+    acc_sum += (am_t == am_q) ? 1.0 : 0.0;
+    for (int j = 0; j < nreg; ++j) {
+      const float mask = y2[(long long)rr * 2 * nreg + j], tgt = y2[(long long)rr * 2 * nreg + nreg + j];
+      const float x = tgt - pregr[(long long)rr * nreg + j], ax = fabsf(x);
+      mask_sum += mask;
+      sl_sum += mask * (ax <= 1.0f ? 0.5f * x * x : ax - 0.5f);
+    }
+  }
+  ce_sum = wave_sum_d(ce_sum); acc_sum = wave_sum_d(acc_sum); mask_sum = wave_sum_d(mask_sum); sl_sum = wave_sum_d(sl_sum);
+  if (lane == 0) { red[wave][0] = ce_sum; red[wave][1] = acc_sum; red[wave][2] = mask_sum; red[wave][3] = sl_sum; }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0, a = 0, ms = 0, sl = 0;
+    for (int wv = 0; wv < 4; ++wv) { c += red[wv][0]; a += red[wv][1]; ms += red[wv][2]; sl += red[wv][3]; }
+    const float den = (float)(1e-4 * (double)r * nreg + ms);
+    s_den = den;
+    losses[0] = (float)(c / r);
+    losses[1] = (float)(sl / (double)den);
+    losses[2] = (float)(a / r);
+  }
+  __syncthreads();
+  const float den = s_den;
+  const int nout = nc + nreg;
+  for (int rr = tid; rr < r; rr += blockDim.x) {
+    const float* q = pcls + (long long)rr * nc;
+    const float* t = y1 + (long long)rr * nc;
+    float S = 0.f;
+    for (int i = 0; i < nc; ++i) S += q[i];
+    // a_k = -t_k*inrange_k/oc_k ; dq_j = (a_j - sum_k a_k o_k)/S/R ; dlogit_i = q_i (dq_i - sum_j dq_j q_j)
+    float sum_ao = 0.f;
+    for (int i = 0; i < nc; ++i) {
+      float o = q[i] / S, oc = fminf(fmaxf(o, lo), hi);
+      float ak = (o >= lo && o <= hi) ? -t[i] / oc : 0.f;
+      sum_ao += ak * o;
+    }
+    float sum_dqq = 0.f;
+    for (int i = 0; i < nc; ++i) {
+      float o = q[i] / S, oc = fminf(fmaxf(o, lo), hi);
+      float ak = (o >= lo && o <= hi) ? -t[i] / oc : 0.f;
+      sum_dqq += (ak - sum_ao) / S / (float)r * q[i];
+    }
+    for (int i = 0; i < nc; ++i) {
+      float o = q[i] / S, oc = fminf(fmaxf(o, lo), hi);
+      float ak = (o >= lo && o <= hi) ? -t[i] / oc : 0.f;
+      float dq = (ak - sum_ao) / S / (float)r;
+      dz[(long long)rr * nout + i] = q[i] * (dq - sum_dqq);
+    }
+    for (int j = 0; j < nreg; ++j) {
+      const float mask = y2[(long long)rr * 2 * nreg + j], tgt = y2[(long long)rr * 2 * nreg + nreg + j];
+      const float x = tgt - pregr[(long long)rr * nreg + j], ax = fabsf(x);
+      const float d = ax <= 1.0f ? x : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+      dz[(long long)rr * nout + nc + j] = -(mask * d) / den;
+    }
+  }
+}
+
+// ---- misc --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ img, long long npix, int cpad, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const float b = (float)img[3 * i + 0] - 103.939f, g = (float)img[3 * i + 1] - 116.779f, r = (float)img[3 * i + 2] - 123.68f;
+    float* o = out + i * cpad;
+    o[0] = b; o[1] = g; o[2] = r;
+    for (int c = 3; c < cpad; ++c) o[c] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, long long n, float alpha) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= alpha;
+}
+
+__global__ void __launch_bounds__(256) affine_vec_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ c, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a[i] * b[i] + c[i];
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 4096) {
+  long long b = (total + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int radnet_maxpool_fwd(radnet_ctx* ctx, const float* x, float* y, int32_t nb, int32_t h, int32_t w, int32_t c, int32_t k, int32_t s) {
+  if (!ctx || !x || !y) return RADNET_ERR_ARG;
+  if (c % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "maxpool: c=%d not a multiple of 4", c);
+  const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+  if (oh <= 0 || ow <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "maxpool: empty output");
+  const long long total = (long long)nb * oh * ow * (c / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, y, nb, h, w, c / 4, oh, ow, k, s);
+  RADNET_CHECK_LAUNCH(ctx, "maxpool");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_roi_resize_fwd(radnet_ctx* ctx, const float* fmap, int32_t h, int32_t w, int32_t c, const float* rois, int32_t r,
+                                     int32_t ps, float* y) {
+  if (!ctx || !fmap || !rois || !y) return RADNET_ERR_ARG;
+  if (c % 4 || r <= 0 || ps <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "roi_resize: bad c=%d r=%d ps=%d", c, r, ps);
+  const int threads = (c / 4) >= 256 ? 256 : (((c / 4) + 63) / 64) * 64;
+  hipLaunchKernelGGL(roi_resize_fwd_kernel, dim3(r * ps * ps), dim3(threads), 0, ctx->stream, fmap, h, w, c / 4, rois, ps, y);
+  RADNET_CHECK_LAUNCH(ctx, "roi_resize_fwd");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_roi_resize_bwd(radnet_ctx* ctx, const float* dy, int32_t h, int32_t w, int32_t c, const float* rois, int32_t r,
+                                     int32_t ps, float* dfmap) {
+  if (!ctx || !dy || !rois || !dfmap) return RADNET_ERR_ARG;
+  hipLaunchKernelGGL(roi_resize_bwd_kernel, dim3(r * ps * ps), dim3(256), 0, ctx->stream, dy, h, w, c, rois, ps, dfmap);
+  RADNET_CHECK_LAUNCH(ctx, "roi_resize_bwd");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_avgpool_fwd(radnet_ctx* ctx, const float* x, int32_t r, int32_t hw, int32_t c, float* y) {
+  if (!ctx || !x || !y) return RADNET_ERR_ARG;
+  if (c % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "avgpool: c %% 4");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(radnet_cdiv((long long)r * (c / 4), 256)), dim3(256), 0, ctx->stream, x, r, hw, c / 4, y);
+  RADNET_CHECK_LAUNCH(ctx, "avgpool_fwd");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_avgpool_bwd_relu(radnet_ctx* ctx, const float* dfeat, const float* y_act, int32_t r, int32_t hw, int32_t c, float* dx) {
+  if (!ctx || !dfeat || !y_act || !dx) return RADNET_ERR_ARG;
+  if (c % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "avgpool_bwd: c %% 4");
+  hipLaunchKernelGGL(avgpool_bwd_relu_kernel, dim3(grid_for((long long)r * hw * (c / 4))), dim3(256), 0, ctx->stream, dfeat, y_act, r, hw,
+                     c / 4, dx);
+  RADNET_CHECK_LAUNCH(ctx, "avgpool_bwd_relu");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_dense_heads_fwd(radnet_ctx* ctx, const float* feat, int32_t r, int32_t k, const float* w, int32_t ldw, const float* b,
+                                      int32_t nc, int32_t nreg, float* out_cls, float* out_regr) {
+  if (!ctx || !feat || !w || !b || !out_cls || !out_regr) return RADNET_ERR_ARG;
+  if (nc + nreg > ldw || (ldw != 32 && ldw != 64)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "dense_heads: ldw=%d must be 32 or 64 and >= nc+nreg=%d", ldw, nc + nreg);
+  if (ldw == 32) hipLaunchKernelGGL(dense_heads_fwd_kernel<32>, dim3(r), dim3(256), 0, ctx->stream, feat, k, w, b, nc, nreg, out_cls, out_regr);
+  else hipLaunchKernelGGL(dense_heads_fwd_kernel<64>, dim3(r), dim3(256), 0, ctx->stream, feat, k, w, b, nc, nreg, out_cls, out_regr);
+  RADNET_CHECK_LAUNCH(ctx, "dense_heads_fwd");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_dense_heads_bwd(radnet_ctx* ctx, const float* feat, const float* dz, int32_t r, int32_t k, const float* w, int32_t ldw,
+                                      int32_t nout, float* dw, float* db, float* dfeat) {
+  if (!ctx || !feat || !dz || !w || !dw || !db || !dfeat) return RADNET_ERR_ARG;
+  const size_t smem = (size_t)r * ldw * sizeof(float);
+  if (smem > 64 * 1024) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "dense_heads_bwd: r=%d too large", r);
+  hipLaunchKernelGGL(dense_heads_bwd_kernel, dim3(radnet_cdiv(k, 8)), dim3(256), smem, ctx->stream, feat, dz, r, k, w, ldw, nout, dw, db, dfeat);
+  RADNET_CHECK_LAUNCH(ctx, "dense_heads_bwd");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t n, int32_t ld, const float* gscale, float* out,
+                             int32_t accumulate) {
+  if (!ctx || !g || !out) return RADNET_ERR_ARG;
+  if (!accumulate) RADNET_CHECK_HIP(ctx, hipMemsetAsync(out, 0, (size_t)n * sizeof(float), ctx->stream));
+  const int rows_per_block = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3(radnet_cdiv(n, 64), radnet_cdiv(m, rows_per_block)), dim3(256), 0, ctx->stream, g, m, n, ld, gscale,
+                     out, rows_per_block);
+  RADNET_CHECK_LAUNCH(ctx, "colsum");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_adam_step(radnet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
+                                float beta2, float eps, float grad_scale) {
+  if (!ctx || !p || !g || !m || !v) return RADNET_ERR_ARG;
+  if (n % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: arena length must be a multiple of 4");
+  if (t < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: step counter starts at 1");
+  // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (keras.optimizers.Adam.get_updates)
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
+                     beta1, beta2, eps, grad_scale);
+  RADNET_CHECK_LAUNCH(ctx, "adam");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_rpn_loss(radnet_ctx* ctx, const float* pred, int32_t ld_pred, const float* y_cls, const float* y_regr, int32_t m,
+                               int32_t a, int32_t bce_mode, float* dz, int32_t ld_dz, float* losses, double* scratch8) {
+  if (!ctx || !pred || !y_cls || !y_regr || !dz || !losses || !scratch8) return RADNET_ERR_ARG;
+  if (ld_pred < 5 * a || ld_dz < 5 * a) RADNET_FAIL(ctx, RADNET_ERR_ARG, "rpn_loss: leading dims too small");
+  RADNET_CHECK_HIP(ctx, hipMemsetAsync(scratch8, 0, 8 * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(rpn_loss_sums_kernel, dim3(grid_for((long long)m * 5 * a, 256, 1024)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
+                     y_regr, m, a, bce_mode, scratch8);
+  RADNET_CHECK_LAUNCH(ctx, "rpn_loss_sums");
+  hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(grid_for((long long)m * ld_dz, 256, 2048)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
+                     y_regr, m, a, bce_mode, scratch8, dz, ld_dz, losses);
+  RADNET_CHECK_LAUNCH(ctx, "rpn_loss_grad");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_det_loss(radnet_ctx* ctx, const float* p_cls, const float* p_regr, const float* y1, const float* y2, int32_t r,
+                               int32_t nc, int32_t nreg, float* dz, float* losses) {
+  if (!ctx || !p_cls || !p_regr || !y1 || !y2 || !dz || !losses) return RADNET_ERR_ARG;
+  hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(256), 0, ctx->stream, p_cls, p_regr, y1, y2, r, nc, nreg, dz, losses);
+  RADNET_CHECK_LAUNCH(ctx, "det_loss");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_preprocess_bgr(radnet_ctx* ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cpad, float* out) {
+  if (!ctx || !img || !out || cpad < 3) return RADNET_ERR_ARG;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((long long)h * w)), dim3(256), 0, ctx->stream, img, (long long)h * w, cpad, out);
+  RADNET_CHECK_LAUNCH(ctx, "preprocess");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_fill_zero(radnet_ctx* ctx, void* p, uint64_t bytes) {
+  if (!ctx || !p) return RADNET_ERR_ARG;
+  RADNET_CHECK_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+  return RADNET_OK;
+}
+
+extern "C" int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha) {
+  if (!ctx || !x) return RADNET_ERR_ARG;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, (long long)n, alpha);
+  RADNET_CHECK_LAUNCH(ctx, "scale");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_affine_vec(radnet_ctx* ctx, float* out, const float* a, const float* b, const float* c, int64_t n) {
+  if (!ctx || !out || !a || !b || !c) return RADNET_ERR_ARG;
+  hipLaunchKernelGGL(affine_vec_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, out, a, b, c, (long long)n);
+  RADNET_CHECK_LAUNCH(ctx, "affine_vec");
+  return RADNET_OK;
+}

@@ -1,0 +1,276 @@
+// Proposal decode + greedy NMS in fp64 with the reference's exact arithmetic (rpn.py:68-172,
+// 299-344, 380-455).  Compiled with -ffp-contract=off: NumPy rounds every product and sum
+// separately, so no FMA contraction is allowed here.
+//
+//   decode   one thread per anchor (a,row,col): delta decode, round-half-even, clamp, clip, validity;
+//            emits a 64-bit sort key (order-preserving score bits << 32 | flat index), 0 for dropped boxes.
+//   sort     descending device radix sort of the keys (rocPRIM, header-only) -> "stable ascending,
+//            walk from the end": among equal scores the higher flat index comes first.
+//   nms      ONE workgroup of 1024 threads walks the sorted candidates 64 at a time:
+//            (1) 16 waves test the 64 candidates against all picks so far (picks live in LDS),
+//            (2) each wave builds rows of the 64x64 intra-chunk suppression matrix with __ballot,
+//            (3) one lane resolves the chunk sequentially with bit operations and appends picks.
+//            Work is (#candidates examined) x (#picks), not N^2, and stops at max_boxes.
+#include "radnet_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+__device__ __forceinline__ unsigned int sortable_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct DecodeArgs {
+  const float* pred;
+  int ld, rows, cols, a;
+  double std_scaling;
+  int use_regr;
+  double aw[32], ah[32];
+};
+
+__global__ void __launch_bounds__(256) decode_kernel(DecodeArgs g, double4* __restrict__ boxes, unsigned long long* __restrict__ keys,
+                                                     int* __restrict__ n_valid) {
+  const int hw = g.rows * g.cols;
+  const int total = hw * g.a;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int a = idx / hw, pix = idx - a * hw;
+  const int row = pix / g.cols, col = pix - row * g.cols;
+  const float* p = g.pred + (size_t)pix * g.ld;
+  const double aw = g.aw[a], ah = g.ah[a];
+  double x = (double)col - aw / 2, y = (double)row - ah / 2, w = aw, h = ah;
+  if (g.use_regr) {
+    const float ss = (float)g.std_scaling;
+    const float tx = p[g.a + 4 * a + 0] / ss, ty = p[g.a + 4 * a + 1] / ss;
+    const float tw = p[g.a + 4 * a + 2] / ss, th = p[g.a + 4 * a + 3] / ss;
+    const double cx = x + w / 2., cy = y + h / 2.;
+    const double cx1 = (double)tx * w + cx, cy1 = (double)ty * h + cy;
+    const double w1 = exp((double)tw) * w, h1 = exp((double)th) * h;
+    x = rint(cx1 - w1 / 2.);
+    y = rint(cy1 - h1 / 2.);
+    w = rint(w1);
+    h = rint(h1);
+  }
+  w = fmax(1.0, w);
+  h = fmax(1.0, h);
+  double x2 = w + x, y2 = h + y;
+  const double x1 = fmax(0.0, x), y1 = fmax(0.0, y);
+  x2 = fmin((double)(g.cols - 1), x2);
+  y2 = fmin((double)(g.rows - 1), y2);
+  // rpn.py:163: drop where (x1 - x2 >= 0) | (y1 - y2 >= 0); NaN boxes (the reference would assert) are dropped too
+  const bool ok = (x1 < x2) && (y1 < y2);
+  boxes[idx] = make_double4(x1, y1, x2, y2);
+  unsigned long long key = 0ull;
+  if (ok) {
+    key = ((unsigned long long)sortable_bits(p[a]) << 32) | (unsigned int)idx;
+    atomicAdd(n_valid, 1);
+  }
+  keys[idx] = key;
+}
+
+__global__ void __launch_bounds__(256) nms_keys_kernel(const double* __restrict__ boxes, const float* __restrict__ probs, int n,
+                                                       unsigned long long* __restrict__ keys, int* __restrict__ n_valid,
+                                                       int* __restrict__ malformed) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const double x1 = boxes[4 * idx], y1 = boxes[4 * idx + 1], x2 = boxes[4 * idx + 2], y2 = boxes[4 * idx + 3];
+  if (!(x1 < x2) || !(y1 < y2)) atomicAdd(malformed, 1);     // rpn.py:400-401 asserts
+  keys[idx] = ((unsigned long long)sortable_bits(probs[idx]) << 32) | (unsigned int)idx;
+  if (idx == 0) *n_valid = n;
+}
+
+__device__ __forceinline__ bool suppresses(const double4& pk, double pk_area, const double4& c, double c_area, double thr) {
+  // rpn.py:429-447 with i = the picked box
+  const double ww = fmax(0.0, fmin(pk.z, c.z) - fmax(pk.x, c.x));
+  const double hh = fmax(0.0, fmin(pk.w, c.w) - fmax(pk.y, c.y));
+  const double inter = ww * hh;
+  const double uni = pk_area + c_area - inter;
+  return inter / (uni + 1e-6) > thr;
+}
+
+constexpr int kMaxPicks = 1024;
+
+__global__ void __launch_bounds__(1024) nms_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ n_valid_p,
+                                                   const int* __restrict__ malformed, const double4* __restrict__ boxes, double thr,
+                                                   int max_boxes, int* __restrict__ out_idx, int* __restrict__ out_count,
+                                                   long long* __restrict__ out_boxes, float* __restrict__ out_probs,
+                                                   const float* __restrict__ probs_src, int probs_stride, int probs_div) {
+  __shared__ double4 pick_box[kMaxPicks];
+  __shared__ double pick_area[kMaxPicks];
+  __shared__ int pick_idx[kMaxPicks];
+  __shared__ double4 cand_box[64];
+  __shared__ double cand_area[64];
+  __shared__ int cand_idx[64];
+  __shared__ unsigned int sup[2];
+  __shared__ unsigned long long mat[64];
+  __shared__ int s_npicks;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_valid = *n_valid_p;
+  if (malformed != nullptr && *malformed != 0) {
+    if (tid == 0) *out_count = -1;
+    return;
+  }
+  if (tid == 0) s_npicks = 0;
+  __syncthreads();
+
+  for (int base = 0; base < n_valid; base += 64) {
+    const int nc = min(64, n_valid - base);
+    if (tid < 64) {
+      if (tid < nc) {
+        const int id = (int)(keys[base + tid] & 0xFFFFFFFFull);
+        const double4 b = boxes[id];
+        cand_idx[tid] = id;
+        cand_box[tid] = b;
+        cand_area[tid] = (b.z - b.x) * (b.w - b.y);
+      }
+      if (tid < 2) sup[tid] = 0u;
+    }
+    __syncthreads();
+    const int npicks = s_npicks;
+    // (1) candidates vs existing picks: lane = candidate, wave = slice of the pick list
+    {
+      bool dead = false;
+      if (lane < nc) {
+        const double4 c = cand_box[lane];
+        const double ca = cand_area[lane];
+        for (int p = wave; p < npicks && !dead; p += 16) dead = suppresses(pick_box[p], pick_area[p], c, ca, thr);
+      }
+      const unsigned long long m = __ballot(dead);
+      if (lane == 0 && m) {
+        atomicOr(&sup[0], (unsigned int)(m & 0xFFFFFFFFull));
+        atomicOr(&sup[1], (unsigned int)(m >> 32));
+      }
+    }
+    // (2) intra-chunk matrix: wave handles rows j = wave, wave+16, ...; lane = victim i (> j)
+    for (int j = wave; j < 64; j += 16) {
+      bool hit = false;
+      if (j < nc && lane < nc && lane > j) hit = suppresses(cand_box[j], cand_area[j], cand_box[lane], cand_area[lane], thr);
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) mat[j] = m;
+    }
+    __syncthreads();
+    // (3) sequential resolve of this chunk
+    if (tid == 0) {
+      unsigned long long alive = ~(((unsigned long long)sup[1] << 32) | sup[0]);
+      if (nc < 64) alive &= (1ull << nc) - 1ull;
+      int np = npicks;
+      for (int j = 0; j < nc && np < max_boxes; ++j) {
+        if ((alive >> j) & 1ull) {
+          pick_box[np] = cand_box[j];
+          pick_area[np] = cand_area[j];
+          pick_idx[np] = cand_idx[j];
+          ++np;
+          alive &= ~mat[j];
+        }
+      }
+      s_npicks = np;
+    }
+    __syncthreads();
+    if (s_npicks >= max_boxes) break;
+  }
+  const int np = s_npicks;
+  if (tid == 0) *out_count = np;
+  for (int i = tid; i < np; i += blockDim.x) {
+    const int id = pick_idx[i];
+    if (out_idx) out_idx[i] = id;
+    if (out_boxes) {
+      const double4 b = pick_box[i];
+      out_boxes[4 * i + 0] = (long long)b.x;     // astype('int'): truncation
+      out_boxes[4 * i + 1] = (long long)b.y;
+      out_boxes[4 * i + 2] = (long long)b.z;
+      out_boxes[4 * i + 3] = (long long)b.w;
+    }
+    if (out_probs) {
+      // flat index = a*hw + pix  ->  pred[pix*ld + a]
+      const int a = id / probs_div, pix = id - a * probs_div;
+      out_probs[i] = probs_src[(size_t)pix * probs_stride + a];
+    }
+  }
+}
+
+struct WsLayout {
+  unsigned long long* keys_in;
+  unsigned long long* keys_out;
+  double4* boxes;
+  int* counters;      // [0] n_valid, [1] malformed
+  void* temp;
+  size_t temp_bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+WsLayout carve(void* ws, int64_t n) {
+  char* p = (char*)ws;
+  WsLayout L;
+  L.keys_in = (unsigned long long*)p;  p += align_up((size_t)n * 8, 256);
+  L.keys_out = (unsigned long long*)p; p += align_up((size_t)n * 8, 256);
+  L.boxes = (double4*)p;               p += align_up((size_t)n * 32, 256);
+  L.counters = (int*)p;                p += 256;
+  L.temp = p;
+  L.temp_bytes = (size_t)n * 16 + (4u << 20);
+  return L;
+}
+
+int sort_desc(radnet_ctx* ctx, const WsLayout& L, int64_t n) {
+  size_t need = 0;
+  hipError_t e = rocprim::radix_sort_keys_desc(nullptr, need, L.keys_in, L.keys_out, (size_t)n, 0, 64, ctx->stream);
+  if (e != hipSuccess) RADNET_FAIL(ctx, RADNET_ERR_HIP, "radix sort size query: %s", hipGetErrorString(e));
+  if (need > L.temp_bytes) RADNET_FAIL(ctx, RADNET_ERR_ARG, "radix sort needs %zu bytes of scratch, workspace has %zu", need, L.temp_bytes);
+  e = rocprim::radix_sort_keys_desc(L.temp, need, L.keys_in, L.keys_out, (size_t)n, 0, 64, ctx->stream);
+  if (e != hipSuccess) RADNET_FAIL(ctx, RADNET_ERR_HIP, "radix sort: %s", hipGetErrorString(e));
+  return RADNET_OK;
+}
+
+}  // namespace
+
+extern "C" uint64_t radnet_proposals_ws_bytes(int64_t n) {
+  return (uint64_t)(align_up((size_t)n * 8, 256) * 2 + align_up((size_t)n * 32, 256) + 256 + (size_t)n * 16 + (4u << 20));
+}
+
+extern "C" int radnet_rpn_to_roi(radnet_ctx* ctx, const float* pred, int32_t ld_pred, int32_t rows, int32_t cols, int32_t a,
+                                 const double* anchor_wh_host, double std_scaling, int32_t use_regr, double overlap_thresh,
+                                 int32_t max_boxes, int64_t* out_boxes, float* out_probs, int32_t* out_count, void* ws) {
+  if (!ctx || !pred || !anchor_wh_host || !out_boxes || !out_count || !ws) return RADNET_ERR_ARG;
+  if (a < 1 || a > 32) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "rpn_to_roi: %d anchors per location (max 32)", a);
+  if (max_boxes < 1 || max_boxes > kMaxPicks) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "rpn_to_roi: max_boxes %d (max %d)", max_boxes, kMaxPicks);
+  if (ld_pred < 5 * a) RADNET_FAIL(ctx, RADNET_ERR_ARG, "rpn_to_roi: ld_pred %d < 5*A", ld_pred);
+  const int64_t n = (int64_t)rows * cols * a;
+  WsLayout L = carve(ws, n);
+  DecodeArgs g{};
+  g.pred = pred; g.ld = ld_pred; g.rows = rows; g.cols = cols; g.a = a; g.std_scaling = std_scaling; g.use_regr = use_regr;
+  for (int i = 0; i < a; ++i) { g.aw[i] = anchor_wh_host[2 * i]; g.ah[i] = anchor_wh_host[2 * i + 1]; }
+  RADNET_CHECK_HIP(ctx, hipMemsetAsync(L.counters, 0, 256, ctx->stream));
+  hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, L.boxes, L.keys_in, L.counters);
+  RADNET_CHECK_LAUNCH(ctx, "decode");
+  int rc = sort_desc(ctx, L, n);
+  if (rc != RADNET_OK) return rc;
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, ctx->stream, L.keys_out, L.counters, (const int*)nullptr, L.boxes, overlap_thresh,
+                     max_boxes, (int*)nullptr, out_count, (long long*)out_boxes, out_probs, pred, ld_pred, rows * cols);
+  RADNET_CHECK_LAUNCH(ctx, "nms");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_nms(radnet_ctx* ctx, const double* boxes, const float* probs, int32_t n, double overlap_thresh, int32_t max_boxes,
+                          int32_t* out_idx, int32_t* out_count, void* ws) {
+  if (!ctx || !out_idx || !out_count || !ws) return RADNET_ERR_ARG;
+  if (max_boxes < 1 || max_boxes > kMaxPicks) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "nms: max_boxes %d (max %d)", max_boxes, kMaxPicks);
+  if (n <= 0) {      // rpn.py:391-392: no boxes -> empty result
+    RADNET_CHECK_HIP(ctx, hipMemsetAsync(out_count, 0, sizeof(int32_t), ctx->stream));
+    return RADNET_OK;
+  }
+  if (!boxes || !probs) return RADNET_ERR_ARG;
+  if (((uintptr_t)boxes & 31)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "nms: boxes must be 32-byte aligned");
+  WsLayout L = carve(ws, n);
+  RADNET_CHECK_HIP(ctx, hipMemsetAsync(L.counters, 0, 256, ctx->stream));
+  hipLaunchKernelGGL(nms_keys_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, boxes, probs, n, L.keys_in, L.counters, L.counters + 1);
+  RADNET_CHECK_LAUNCH(ctx, "nms_keys");
+  int rc = sort_desc(ctx, L, n);
+  if (rc != RADNET_OK) return rc;
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, ctx->stream, L.keys_out, L.counters, L.counters + 1, (const double4*)boxes,
+                     overlap_thresh, max_boxes, out_idx, out_count, (long long*)nullptr, (float*)nullptr, (const float*)nullptr, 0, 1);
+  RADNET_CHECK_LAUNCH(ctx, "nms");
+  return RADNET_OK;
+}

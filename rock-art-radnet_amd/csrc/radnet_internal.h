@@ -1,0 +1,61 @@
+// Internal definitions shared by the gfx950 kernel translation units of libradnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "radnet_hip.h"
+
+struct radnet_timing_slot {
+  double ms = 0.0;
+  double flops = 0.0;
+  int64_t launches = 0;
+};
+
+struct radnet_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  void* ws = nullptr;
+  uint64_t ws_bytes = 0;
+  // timing of GEMM-class launches with HIP events on `stream` (bench roofline leg)
+  int timing = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  radnet_timing_slot slots[3];
+  // pending (not yet resolved) event pairs are resolved lazily to avoid a sync per launch
+  static constexpr int kMaxPending = 4096;
+  hipEvent_t pend0[kMaxPending];
+  hipEvent_t pend1[kMaxPending];
+  int pend_cls[kMaxPending];
+  double pend_flops[kMaxPending];
+  int n_pending = 0;
+  int n_events_alloc = 0;
+};
+
+#define RADNET_FAIL(ctx, code, ...)                         \
+  do {                                                      \
+    snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__);  \
+    return (code);                                          \
+  } while (0)
+
+#define RADNET_CHECK_HIP(ctx, expr)                                                              \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) RADNET_FAIL(ctx, RADNET_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define RADNET_CHECK_LAUNCH(ctx, what)                                                              \
+  do {                                                                                              \
+    hipError_t _e = hipGetLastError();                                                              \
+    if (_e != hipSuccess) RADNET_FAIL(ctx, RADNET_ERR_HIP, "launch %s: %s", what, hipGetErrorString(_e)); \
+  } while (0)
+
+// timing helpers (api.cpp)
+void radnet_timing_begin(radnet_ctx* ctx);
+void radnet_timing_end(radnet_ctx* ctx, int cls, double flops);
+
+static inline int radnet_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// exact floor(m / d) for m, d < 2^20 as (m * magic) >> 40  (m*d < 2^40, see conv_mfma.hip)
+static inline uint64_t radnet_div_magic(uint32_t d) { return ((1ull << 40) + d - 1) / d; }

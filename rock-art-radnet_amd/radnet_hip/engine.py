@@ -1,0 +1,638 @@
+"""Device-side engine of the MI355X-native Faster R-CNN path.
+
+Python here is a *scheduler*: it owns the weight / activation buffers (torch-ROCm tensors used purely
+as containers), lays the reference's Keras graph out as a static list of kernel launches per image
+size, and calls libradnet_hip.so through the C ABI (radnet_hip.lib).  No torch arithmetic runs on the
+hot path.
+
+Graph restated from the reference (never imported):
+  base   faster_rcnn/base_models/resnet50.py:150-228   conv1 + stages 2-4, frozen BN folded into epilogues
+  RPN    faster_rcnn/rpn.py:12-66                      3x3 conv + ONE fused 1x1 GEMM for both heads
+  head   faster_rcnn/base_models/resnet50.py:231-281   RoI crop-resize 14x14 + stage 5 + avgpool + dense
+  step   train.py:288-402                              RPN train -> re-predict -> propose/label/sample -> head train
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+BN_EPS = 1e-3        # FixedBatchNormalization.py:8
+RES_STAGES = ((2, "abc", (64, 64, 256), 1), (3, "abcd", (128, 128, 512), 2), (4, "abcdef", (256, 256, 1024), 2))
+HEAD_STAGE = (5, "abc", (512, 512, 2048), 2)
+RPN_LD = 64          # fused RPN head GEMM width (A + 4A = 60 for 12 anchors, padded)
+
+
+def feat_len(n):
+    """resnet50.get_img_output_length (resnet50.py:19-35)."""
+    n += 6
+    for k in (7, 3, 1, 1):
+        n = (n - k + 2) // 2
+    return n
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class Arena:
+    """One flat fp32 parameter arena (+ grads, Adam moments) with named views: a single Adam launch and a
+    single all-reduce cover every tensor of an optimizer (train.py:236-252 has one Adam per model)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.spec = []       # (name, shape)
+        self.views = {}
+        self.offsets = {}
+        self.n = 0
+
+    def add(self, name, shape):
+        size = int(np.prod(shape))
+        self.spec.append((name, tuple(shape)))
+        self.offsets[name] = (self.n, size)
+        self.n += _pad4(size)
+
+    def finalize(self):
+        self.n = (self.n + 255) // 256 * 256
+        self.p = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.t = 0
+        for name, shape in self.spec:
+            o, s = self.offsets[name]
+            self.views[name] = self.p[o:o + s].view(shape)
+            self.views["d:" + name] = self.g[o:o + s].view(shape)
+
+    def param(self, name):
+        return self.views[name]
+
+    def grad(self, name):
+        return self.views["d:" + name]
+
+
+class ConvLayer:
+    """One convolution of the static layer program (descriptor prebuilt; pointers are stable)."""
+
+    def __init__(self, name, kh, cin, cout, stride=1, pad=0, ldw=None):
+        self.name, self.kh, self.cin, self.cout, self.stride, self.pad = name, kh, cin, cout, stride, pad
+        self.ldw = ldw or cout
+        self.weight = None      # [kh*kh*cin][ldw]
+        self.bias = None        # [cout] raw conv bias
+        self.scale = None       # folded BN scale or None
+        self.shift = None       # folded epilogue shift
+        self.t0 = None          # BN shift without the conv bias (trainable convs refresh shift = scale*bias + t0)
+        self.dweight = None
+        self.dbias = None
+
+
+class FasterRCNNEngine:
+    """ResNet50 Faster R-CNN on one MI355X.  `mode`: 'train' = train.py trainability (whole base frozen);
+    inference uses the same object."""
+
+    def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5):
+        if C_cfg.network != "resnet50":
+            raise L.RadnetError("engine: network %r not built yet (resnet50 only)" % (C_cfg.network,))
+        self.C = C_cfg
+        self.dev = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.dev)
+        self.ctx = L.Context(device_index)
+        self.lib = self.ctx.lib
+        self.A = len(C_cfg.anchor_box_scales) * len(C_cfg.anchor_box_ratios)
+        self.nc = n_classes or len(C_cfg.class_mapping)
+        self.nreg = 4 * (self.nc - 1)
+        self.bg = C_cfg.class_mapping.get("bg", self.nc - 1)
+        self.bce_mode = bce_mode
+        self.lr = lr
+        if 5 * self.A > RPN_LD:
+            raise L.RadnetError("engine: %d anchors exceed the fused RPN head width" % self.A)
+        self.dense_ld = 32 if self.nc + self.nreg <= 32 else 64
+        self._build_layers()
+        self._plans = {}
+        self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
+        self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
+        self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
+                                   for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
+        self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)
+        self.anchor_ratios = np.array(C_cfg.anchor_box_ratios, dtype=np.float64).reshape(-1, 2)
+        self.regr_std = np.array(C_cfg.classifier_regr_std, dtype=np.float64)
+        self.loss_scratch = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self.rpn_losses = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        self.det_losses = torch.zeros(3, dtype=torch.float32, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------ layers
+    def _build_layers(self):
+        dev = self.dev
+        self.base_layers = []           # execution order, tuples describing the program
+        self.convs = {}
+        frozen_elems = 0
+
+        def conv(name, kh, cin, cout, stride=1, pad=0, ldw=None):
+            c = ConvLayer(name, kh, cin, cout, stride, pad, ldw)
+            self.convs[name] = c
+            return c
+
+        conv("conv1", 7, 4, 64, 2, 3)                       # image padded to 4 channels
+        cin = 64
+        for st, blocks, (f1, f2, f3), stride in RES_STAGES + (HEAD_STAGE,):
+            if st == 5:
+                cin = 1024
+            for bl in blocks:
+                b = "res%d%s_branch" % (st, bl)
+                first = bl == "a"
+                conv(b + "2a", 1, cin, f1, stride if first else 1)
+                conv(b + "2b", 3, f1, f2, 1, 1)
+                conv(b + "2c", 1, f2, f3)
+                if first:
+                    conv(b + "1", 1, cin, f3, stride)
+                cin = f3
+        conv("rpn_conv1", 3, 1024, 512, 1, 1)
+        conv("rpn_heads", 1, 512, 5 * self.A, 1, 0, ldw=RPN_LD)
+
+        # frozen base: plain tensors
+        for name, c in self.convs.items():
+            if name.startswith(("res5", "rpn")):
+                continue
+            c.weight = torch.zeros(c.kh * c.kh * c.cin, c.ldw, dtype=torch.float32, device=dev)
+            c.scale = torch.ones(c.cout, dtype=torch.float32, device=dev)
+            c.shift = torch.zeros(c.cout, dtype=torch.float32, device=dev)
+
+        # RPN optimizer arena (rpn.py:41-64: no BN, bias straight into the epilogue shift)
+        self.rpn_arena = Arena(dev)
+        for name in ("rpn_conv1", "rpn_heads"):
+            c = self.convs[name]
+            self.rpn_arena.add(name + "/kernel", (c.kh * c.kh * c.cin, c.ldw))
+            self.rpn_arena.add(name + "/bias", (c.ldw,))
+        self.rpn_arena.finalize()
+        for name in ("rpn_conv1", "rpn_heads"):
+            c = self.convs[name]
+            c.weight, c.bias = self.rpn_arena.param(name + "/kernel"), self.rpn_arena.param(name + "/bias")
+            c.dweight, c.dbias = self.rpn_arena.grad(name + "/kernel"), self.rpn_arena.grad(name + "/bias")
+            c.shift = c.bias
+
+        # classifier-head optimizer arena: all stage-5 kernels, then all stage-5 biases contiguous (so one
+        # affine_vec launch refreshes every folded shift), then the dense heads
+        self.head_arena = Arena(dev)
+        head_names = [n for n in self.convs if n.startswith("res5")]
+        self.head_conv_names = head_names
+        for name in head_names:
+            c = self.convs[name]
+            self.head_arena.add(name + "/kernel", (c.kh * c.kh * c.cin, c.cout))
+        self.head_bias_off = self.head_arena.n
+        for name in head_names:
+            self.head_arena.add(name + "/bias", (self.convs[name].cout,))
+        self.head_bias_len = self.head_arena.n - self.head_bias_off
+        self.head_arena.add("dense/kernel", (2048, self.dense_ld))
+        self.head_arena.add("dense/bias", (self.dense_ld,))
+        self.head_arena.finalize()
+        self.head_scale = torch.ones(self.head_bias_len, dtype=torch.float32, device=dev)
+        self.head_t0 = torch.zeros(self.head_bias_len, dtype=torch.float32, device=dev)
+        self.head_shift = torch.zeros(self.head_bias_len, dtype=torch.float32, device=dev)
+        for name in head_names:
+            c = self.convs[name]
+            c.weight, c.bias = self.head_arena.param(name + "/kernel"), self.head_arena.param(name + "/bias")
+            c.dweight, c.dbias = self.head_arena.grad(name + "/kernel"), self.head_arena.grad(name + "/bias")
+            o = self.head_arena.offsets[name + "/bias"][0] - self.head_bias_off
+            c.scale = self.head_scale[o:o + c.cout]
+            c.t0 = self.head_t0[o:o + c.cout]
+            c.shift = self.head_shift[o:o + c.cout]
+        self.dense_w, self.dense_b = self.head_arena.param("dense/kernel"), self.head_arena.param("dense/bias")
+        self.dense_dw, self.dense_db = self.head_arena.grad("dense/kernel"), self.head_arena.grad("dense/bias")
+
+    def refresh_head_shift(self):
+        """shift = scale * bias + t0 for every stage-5 conv (FixedBatchNormalization.py:59-85 folded)."""
+        bias = self.head_arena.p[self.head_bias_off:self.head_bias_off + self.head_bias_len]
+        self.ctx.call("radnet_affine_vec", self.head_shift, self.head_scale, bias, self.head_t0, C.c_int64(self.head_bias_len))
+
+    # ------------------------------------------------------------------------------------------ weights
+    def set_weights(self, W):
+        """Load weights keyed by the reference's Keras layer names: conv/dense {'kernel','bias'} in HWIO /
+        (in,out) layout, FixedBatchNormalization {'gamma','beta','mean','var'} (weight order of
+        FixedBatchNormalization.py:26-51)."""
+        dev = self.dev
+
+        def t(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        def bn_name(conv_name):
+            if conv_name == "conv1":
+                return "bn_conv1"
+            return conv_name.replace("res", "bn", 1)
+
+        for name, c in self.convs.items():
+            if name == "rpn_heads":
+                kc, kr = W["rpn_out_class"], W["rpn_out_regress"]
+                k = np.zeros((512, RPN_LD), np.float32)
+                k[:, :self.A] = kc["kernel"].reshape(512, self.A)
+                k[:, self.A:5 * self.A] = kr["kernel"].reshape(512, 4 * self.A)
+                b = np.zeros(RPN_LD, np.float32)
+                b[:self.A] = kc["bias"]
+                b[self.A:5 * self.A] = kr["bias"]
+                c.weight.copy_(t(k)); c.bias.copy_(t(b))
+                continue
+            kern = np.asarray(W[name]["kernel"], dtype=np.float32)
+            bias = np.asarray(W[name]["bias"], dtype=np.float32)
+            if name == "conv1":
+                kern = np.concatenate([kern, np.zeros((7, 7, 1, 64), np.float32)], axis=2)
+            c.weight.copy_(t(kern.reshape(-1, c.cout)))
+            if name == "rpn_conv1":
+                c.bias.copy_(t(bias))
+                continue
+            bn = W[bn_name(name)]
+            s = (np.asarray(bn["gamma"], np.float64) / np.sqrt(np.asarray(bn["var"], np.float64) + BN_EPS))
+            t0 = np.asarray(bn["beta"], np.float64) - np.asarray(bn["mean"], np.float64) * s
+            c.scale.copy_(t(s))
+            if c.bias is None:                      # frozen: fold the bias once
+                c.shift.copy_(t(s * bias.astype(np.float64) + t0))
+            else:
+                c.bias.copy_(t(bias)); c.t0.copy_(t(t0))
+        dc, dr = W["dense_class_%d" % self.nc], W["dense_regress_%d" % self.nc]
+        k = np.zeros((2048, self.dense_ld), np.float32)
+        k[:, :self.nc] = dc["kernel"]; k[:, self.nc:self.nc + self.nreg] = dr["kernel"]
+        b = np.zeros(self.dense_ld, np.float32)
+        b[:self.nc] = dc["bias"]; b[self.nc:self.nc + self.nreg] = dr["bias"]
+        self.dense_w.copy_(t(k)); self.dense_b.copy_(t(b))
+        self.refresh_head_shift()
+        torch.cuda.synchronize(self.dev)
+
+    def get_weights(self, names=None):
+        """Trainable weights back in Keras layout (host numpy)."""
+        out = {}
+        for name in ["rpn_conv1"] + self.head_conv_names:
+            c = self.convs[name]
+            out[name] = {"kernel": c.weight.detach().cpu().numpy().reshape(c.kh, c.kh, c.cin, c.cout).copy(),
+                         "bias": c.bias.detach().cpu().numpy()[:c.cout].copy()}
+        k = self.convs["rpn_heads"].weight.detach().cpu().numpy()
+        b = self.convs["rpn_heads"].bias.detach().cpu().numpy()
+        out["rpn_out_class"] = {"kernel": k[:, :self.A].reshape(1, 1, 512, self.A).copy(), "bias": b[:self.A].copy()}
+        out["rpn_out_regress"] = {"kernel": k[:, self.A:5 * self.A].reshape(1, 1, 512, 4 * self.A).copy(), "bias": b[self.A:5 * self.A].copy()}
+        k = self.dense_w.detach().cpu().numpy(); b = self.dense_b.detach().cpu().numpy()
+        out["dense_class_%d" % self.nc] = {"kernel": k[:, :self.nc].copy(), "bias": b[:self.nc].copy()}
+        out["dense_regress_%d" % self.nc] = {"kernel": k[:, self.nc:self.nc + self.nreg].copy(), "bias": b[self.nc:self.nc + self.nreg].copy()}
+        return out
+
+    # ------------------------------------------------------------------------------------------ descriptors
+    def _desc(self, c, x, nb, h, w, y, relu=True, addend=None, act=None, act_cols=0):
+        oh = (h + 2 * c.pad - c.kh) // c.stride + 1
+        ow = (w + 2 * c.pad - c.kh) // c.stride + 1
+        d = L.ConvDesc()
+        d.x, d.w, d.y = x.data_ptr(), c.weight.data_ptr(), y.data_ptr()
+        d.scale = c.scale.data_ptr() if c.scale is not None else None
+        d.shift = c.shift.data_ptr() if c.shift is not None else None
+        d.addend = addend.data_ptr() if addend is not None else None
+        d.nb, d.h, d.w_, d.c, d.oh, d.ow = nb, h, w, c.cin, oh, ow
+        d.kh = d.kw = c.kh
+        d.stride, d.pad_t, d.pad_l, d.n = c.stride, c.pad, c.pad, c.ldw if c.name == "rpn_heads" else c.cout
+        d.ldw, d.ldy, d.ld_add = c.ldw, d.n, d.n
+        d.act = (1 if relu else 0) if act is None else act
+        d.act_cols = act_cols
+        return d, oh, ow
+
+    def _plan_base(self, nb, H, W):
+        """Static launch list of nn_base for (nb,H,W) input: [(kind, payload)], output tensor F."""
+        key = ("base", nb, H, W)
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.dev
+        ops, keep = [], []
+
+        def buf(*shape):
+            b = torch.empty(shape, dtype=torch.float32, device=dev)
+            keep.append(b)
+            return b
+
+        x = buf(nb, H, W, 4)
+        c = self.convs["conv1"]
+        oh, ow = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        y = buf(nb, oh, ow, 64)
+        d, _, _ = self._desc(c, x, nb, H, W, y)
+        ops.append(("conv", d))
+        ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+        p = buf(nb, ph, pw, 64)
+        ops.append(("maxpool", (y, p, nb, oh, ow, 64, 3, 2)))
+        cur, h, w = p, ph, pw
+        for st, blocks, (f1, f2, f3), stride in RES_STAGES:
+            for bl in blocks:
+                b = "res%d%s_branch" % (st, bl)
+                first = bl == "a"
+                ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
+                oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
+                a = buf(nb, oh, ow, f1)
+                d, _, _ = self._desc(ca, cur, nb, h, w, a); ops.append(("conv", d))
+                bb = buf(nb, oh, ow, f2)
+                d, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", d))
+                if first:
+                    sc = buf(nb, oh, ow, f3)
+                    d, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False); ops.append(("conv", d))
+                else:
+                    sc = cur
+                out = buf(nb, oh, ow, f3)
+                d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
+                cur, h, w = out, oh, ow
+        plan = dict(ops=ops, x=x, F=cur, fh=h, fw=w, keep=keep)
+        self._plans[key] = plan
+        return plan
+
+    def _run(self, ops):
+        lib, h = self.lib, self.ctx.h
+        for kind, p in ops:
+            if kind == "conv":
+                rc = lib.radnet_conv_fwd(h, C.byref(p))
+            elif kind == "dgrad":
+                rc = lib.radnet_conv_dgrad(h, C.byref(p))
+            elif kind == "wgrad":
+                rc = lib.radnet_conv_wgrad(h, C.byref(p))
+            elif kind == "maxpool":
+                x, y, nb, hh, ww, c, k, s = p
+                rc = lib.radnet_maxpool_fwd(h, x.data_ptr(), y.data_ptr(), nb, hh, ww, c, k, s)
+            elif kind == "colsum":
+                g, m, n, ld, gs, out = p
+                rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, 1)
+            else:
+                raise L.RadnetError("unknown op " + kind)
+            if rc != 0:
+                self.ctx.check(rc, kind)
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def upload_image(self, img_bgr_u8, plan=None):
+        """uint8 BGR HWC host image -> preprocessed fp32 NHWC(4) on device (RADNet.py:83-87)."""
+        H, W = img_bgr_u8.shape[:2]
+        plan = plan or self._plan_base(1, H, W)
+        raw = torch.from_numpy(np.ascontiguousarray(img_bgr_u8)).to(self.dev)
+        self.ctx.call("radnet_preprocess_bgr", raw, H, W, 4, plan["x"])
+        return plan
+
+    def upload_preprocessed(self, X):
+        """X: (1,H,W,3) fp32 already preprocessed by the caller (Keras-style model.predict input)."""
+        _, H, W, _ = X.shape
+        plan = self._plan_base(1, H, W)
+        x4 = np.zeros((1, H, W, 4), np.float32)
+        x4[..., :3] = X
+        plan["x"].copy_(torch.from_numpy(x4).to(self.dev))
+        return plan
+
+    def base_forward(self, plan):
+        self._run(plan["ops"])
+        return plan["F"]
+
+    def _plan_rpn(self, fh, fw, F):
+        key = ("rpn", fh, fw, F.data_ptr())
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.dev
+        M = fh * fw
+        hbuf = torch.empty(1, fh, fw, 512, dtype=torch.float32, device=dev)
+        pred = torch.empty(M, RPN_LD, dtype=torch.float32, device=dev)
+        c1, ch = self.convs["rpn_conv1"], self.convs["rpn_heads"]
+        d1, _, _ = self._desc(c1, F, 1, fh, fw, hbuf, relu=True)
+        d2, _, _ = self._desc(ch, hbuf, 1, fh, fw, pred, act=2, act_cols=self.A)
+        # backward
+        dz = torch.zeros(M, RPN_LD, dtype=torch.float32, device=dev)
+        dh = torch.empty(M, 512, dtype=torch.float32, device=dev)
+        # heads: wgrad + dgrad (masked by relu of rpn_conv1)
+        b2 = L.ConvDesc.from_buffer_copy(d2)
+        b2.dy, b2.ld_dy, b2.gscale = dz.data_ptr(), RPN_LD, None
+        b2.dw, b2.dw_accumulate = ch.dweight.data_ptr(), 1
+        b2.dx, b2.ld_dx, b2.dx_add, b2.dx_mask, b2.ld_dx_mask = dh.data_ptr(), 512, None, hbuf.data_ptr(), 512
+        b1 = L.ConvDesc.from_buffer_copy(d1)
+        b1.dy, b1.ld_dy, b1.gscale = dh.data_ptr(), 512, None
+        b1.dw, b1.dw_accumulate = c1.dweight.data_ptr(), 1
+        bwd = [("wgrad", b2), ("colsum", (dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr())),
+               ("dgrad", b2), ("wgrad", b1), ("colsum", (dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr()))]
+        ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
+        plan = dict(fwd=[("conv", d1), ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw,
+                    prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
+                    R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
+                    Rn=torch.zeros(1, dtype=torch.int32, device=dev))
+        self._plans[key] = plan
+        return plan
+
+    def rpn_forward(self, bplan):
+        rp = self._plan_rpn(bplan["fh"], bplan["fw"], bplan["F"])
+        self._run(rp["fwd"])
+        return rp
+
+    def rpn_backward(self, rp, y_cls, y_regr):
+        """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
+        self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,
+                      self.rpn_losses, self.loss_scratch)
+        self._run(rp["bwd"])
+
+    def adam(self, arena, grad_scale=1.0):
+        arena.t += 1
+        self.ctx.call("radnet_adam_step", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
+                      C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale))
+
+    def zero_grads(self, arena):
+        self.ctx.call("radnet_fill_zero", arena.g, C.c_uint64(arena.n * 4))
+
+    def proposals(self, rp, overlap_thresh=0.7, max_boxes=300, use_regr=True):
+        """rpn.rpn_to_roi on device; returns (R int64 [max][4] device, count device int32)."""
+        awh = self.anchor_wh.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self.lib.radnet_rpn_to_roi(self.ctx.h, rp["pred"].data_ptr(), RPN_LD, rp["fh"], rp["fw"], self.A, awh,
+                                        float(self.C.std_scaling), 1 if use_regr else 0, float(overlap_thresh), int(max_boxes),
+                                        rp["R"].data_ptr(), rp["Rp"].data_ptr(), rp["Rn"].data_ptr(), rp["prop_ws"].data_ptr())
+        self.ctx.check(rc, "radnet_rpn_to_roi")
+        return rp["R"], rp["Rn"]
+
+    # ------------------------------------------------------------------------------------------ classifier head
+    def _plan_head(self, R, fh, fw, F):
+        key = ("head", R, fh, fw, F.data_ptr())
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.dev
+        keep = []
+
+        def buf(*shape):
+            b = torch.empty(shape, dtype=torch.float32, device=dev)
+            keep.append(b)
+            return b
+
+        rois = buf(R, 4)
+        pooled = buf(R, 14, 14, 1024)
+        fwd, blocks = [], []
+        cur, h, w = pooled, 14, 14
+        st, bls, (f1, f2, f3), stride = HEAD_STAGE
+        for bl in bls:
+            b = "res5%s_branch" % bl
+            first = bl == "a"
+            ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
+            oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
+            a = buf(R, oh, ow, f1); da, _, _ = self._desc(ca, cur, R, h, w, a); fwd.append(("conv", da))
+            bb = buf(R, oh, ow, f2); db, _, _ = self._desc(cb, a, R, oh, ow, bb); fwd.append(("conv", db))
+            ds = None
+            if first:
+                sc = buf(R, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, R, h, w, sc, relu=False); fwd.append(("conv", ds))
+            else:
+                sc = cur
+            out = buf(R, oh, ow, f3); dc, _, _ = self._desc(cc, bb, R, oh, ow, out, relu=True, addend=sc); fwd.append(("conv", dc))
+            blocks.append(dict(first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, names=(b + "2a", b + "2b", b + "2c", b + "1")))
+            cur, h, w = out, oh, ow
+        M = R * h * w
+        feat = buf(R, 2048)
+        pcls, pregr = buf(R, self.nc), buf(R, self.nreg)
+        y1, y2 = buf(R, self.nc), buf(R, 2 * self.nreg)
+        dz = buf(R, self.nc + self.nreg)
+        dfeat = buf(R, 2048)
+        # backward program (train.py mode: nothing flows below the RoI crop, the base is frozen)
+        bwd = []
+        g_out = buf(M, f3)                     # gradient w.r.t. the last block's output, ReLU mask applied
+        g_first = g_out
+        for bi in range(len(blocks) - 1, -1, -1):
+            B = blocks[bi]
+            ca, cb, cc = (self.convs[n] for n in B["names"][:3])
+            g_b, g_a = buf(M, f2), buf(M, f1)
+
+            def bdesc(fdesc, conv, dy, ld_dy, dx=None, ld_dx=0, dx_add=None, dx_mask=None):
+                d = L.ConvDesc.from_buffer_copy(fdesc)
+                d.dy, d.ld_dy, d.gscale = dy.data_ptr(), ld_dy, conv.scale.data_ptr()
+                d.dw, d.dw_accumulate = conv.dweight.data_ptr(), 1
+                if dx is not None:
+                    d.dx, d.ld_dx = dx.data_ptr(), ld_dx
+                    d.dx_add = dx_add.data_ptr() if dx_add is not None else None
+                    d.ld_dx_add = ld_dx
+                    d.dx_mask = dx_mask.data_ptr() if dx_mask is not None else None
+                    d.ld_dx_mask = ld_dx
+                return d
+
+            dC = bdesc(B["dc"], cc, g_out, f3, g_b, f2, None, B["b"])
+            bwd += [("wgrad", dC), ("colsum", (g_out.data_ptr(), M, f3, f3, cc.scale.data_ptr(), cc.dbias.data_ptr())), ("dgrad", dC)]
+            dB = bdesc(B["db"], cb, g_b, f2, g_a, f1, None, B["a"])
+            bwd += [("wgrad", dB), ("colsum", (g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr())), ("dgrad", dB)]
+            if B["first"]:
+                dA = bdesc(B["da"], ca, g_a, f1)
+                bwd += [("wgrad", dA), ("colsum", (g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr()))]
+                cs = self.convs[B["names"][3]]
+                dS = bdesc(B["ds"], cs, g_out, f3)
+                bwd += [("wgrad", dS), ("colsum", (g_out.data_ptr(), M, f3, f3, cs.scale.data_ptr(), cs.dbias.data_ptr()))]
+            else:
+                g_prev = buf(M, f3)            # grad w.r.t. this block's input = previous block's output (post-ReLU)
+                dA = bdesc(B["da"], ca, g_a, f1, g_prev, f3, g_out, B["x"])
+                bwd += [("wgrad", dA), ("colsum", (g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr())), ("dgrad", dA)]
+                g_out = g_prev
+        plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
+                    pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
+        self._plans[key] = plan
+        return plan
+
+    def head_forward(self, hp):
+        self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
+        self._run(hp["fwd"])
+        self.ctx.call("radnet_avgpool_fwd", hp["y5"], hp["R"], hp["hw"], 2048, hp["feat"])
+        self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
+                      hp["pcls"], hp["pregr"])
+
+    def head_backward(self, hp):
+        """losses (losses.py:69-95) + gradients of every stage-5 conv and both dense heads into the head grad arena."""
+        self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"], self.det_losses)
+        self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
+                      self.dense_dw, self.dense_db, hp["dfeat"])
+        self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
+        self._run(hp["bwd"])
+
+    # ------------------------------------------------------------------------------------------ targets
+    def anchor_targets(self, gt_boxes, gt_is_bg, width, height, rw, rh):
+        """utils.calc_region_props: device labelling + host RNG subsampling (utils.py:777-813 stays on the host
+        NumPy global stream by design) + device packing.  Returns (y_cls, y_regr) fp32 NHWC device tensors,
+        best_anchor (host), n_pos.  Raises KeyError exactly where the reference does."""
+        fw, fh = feat_len(rw), feat_len(rh)
+        A = self.A
+        key = ("atgt", fh, fw)
+        if key not in self._plans:
+            dev = self.dev
+            self._plans[key] = dict(valid=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev), overlap=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev),
+                                    regr=torch.zeros(fh, fw, 4 * A, dtype=torch.float64, device=dev),
+                                    ycls=torch.zeros(fh, fw, 2 * A, dtype=torch.float32, device=dev),
+                                    yregr=torch.zeros(fh, fw, 8 * A, dtype=torch.float32, device=dev))
+        P = self._plans[key]
+        g = len(gt_boxes)
+        gt = torch.from_numpy(np.ascontiguousarray(gt_boxes, dtype=np.float64).reshape(-1, 4)).to(self.dev) if g else None
+        isbg = torch.from_numpy(np.ascontiguousarray(gt_is_bg, dtype=np.int32)).to(self.dev) if g else None
+        best = torch.zeros(max(g, 1), 4, dtype=torch.int32, device=self.dev)
+        nfor = torch.zeros(max(g, 1), dtype=torch.int32, device=self.dev)
+        scratch = torch.zeros(max(g, 1), dtype=torch.int64, device=self.dev)
+        rc = self.lib.radnet_anchor_targets(self.ctx.h, gt.data_ptr() if g else None, isbg.data_ptr() if g else None, g, int(width), int(height),
+                                            int(rw), int(rh), fw, fh, self.anchor_sizes.ctypes.data_as(C.POINTER(C.c_double)), len(self.anchor_sizes),
+                                            self.anchor_ratios.ctypes.data_as(C.POINTER(C.c_double)), len(self.anchor_ratios), float(self.C.rpn_stride),
+                                            float(self.C.rpn_max_overlap), P["valid"].data_ptr(), P["overlap"].data_ptr(), P["regr"].data_ptr(),
+                                            best.data_ptr(), nfor.data_ptr(), scratch.data_ptr())
+        self.ctx.check(rc, "radnet_anchor_targets")
+        valid = P["valid"].cpu().numpy()          # D2H (syncs): 2 x A*fh*fw bytes
+        overlap = P["overlap"].cpu().numpy()
+        n_pos = subsample_valid(valid, overlap)
+        P["valid"].copy_(torch.from_numpy(valid))
+        self.ctx.call("radnet_anchor_targets_pack", P["valid"], P["overlap"], P["regr"], fw, fh, A, C.c_double(float(self.C.std_scaling)),
+                      P["ycls"], P["yregr"])
+        best_h = best.cpu().numpy()[:g].astype(np.int64) if g else np.zeros((0, 4), np.int64)
+        return P["ycls"], P["yregr"], best_h, n_pos
+
+    def roi_targets(self, R_dev, n, gt_boxes, gt_cls, width, height, rw, rh):
+        """rpn.calc_iou on device.  Returns host (keep u8 [n], cls i32 [n]) and device (box, t) for packing."""
+        dev = self.dev
+        key = ("rtgt",)
+        if key not in self._plans:
+            self._plans[key] = dict(keep=torch.zeros(1024, dtype=torch.uint8, device=dev), cls=torch.zeros(1024, dtype=torch.int32, device=dev),
+                                    box=torch.zeros(1024, 4, dtype=torch.int32, device=dev), t=torch.zeros(1024, 4, dtype=torch.float64, device=dev),
+                                    iou=torch.zeros(1024, dtype=torch.float64, device=dev))
+        P = self._plans[key]
+        g = len(gt_boxes)
+        gt = torch.from_numpy(np.ascontiguousarray(gt_boxes, dtype=np.float64).reshape(-1, 4)).to(dev)
+        gc = torch.from_numpy(np.ascontiguousarray(gt_cls, dtype=np.int32)).to(dev)
+        rc = self.lib.radnet_roi_targets(self.ctx.h, R_dev.data_ptr(), int(n), gt.data_ptr(), gc.data_ptr(), g, int(width), int(height), int(rw), int(rh),
+                                         float(self.C.rpn_stride), float(self.C.classifier_min_overlap), float(self.C.classifier_max_overlap),
+                                         self.regr_std.ctypes.data_as(C.POINTER(C.c_double)), int(self.bg), P["keep"].data_ptr(), P["cls"].data_ptr(),
+                                         P["box"].data_ptr(), P["t"].data_ptr(), P["iou"].data_ptr())
+        self.ctx.check(rc, "radnet_roi_targets")
+        return P
+
+    def pack_roi_batch(self, P, sel, hp):
+        sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32)).to(self.dev)
+        self.ctx.call("radnet_roi_batch_pack", sel_t, len(sel), P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"], hp["y1"], hp["y2"])
+
+
+def subsample_valid(valid, overlap, max_regions=256):
+    """Host half of utils.calc_region_props (utils.py:777-813): random disabling of surplus positives /
+    negatives on the *global NumPy RNG stream*, which is part of the reference's contract (train.py:41,134).
+    valid / overlap: uint8 [A][fh][fw] (the NCHW order np.where enumerates in the reference); `valid` is
+    edited in place.  Returns n_pos."""
+    pos = np.where((overlap == 1) & (valid == 1))
+    neg = np.where((overlap == 0) & (valid == 1))
+    n_pos, n_neg = len(pos[0]), len(neg[0])
+    half = int(max_regions / 2)
+    if n_pos > max_regions / 2:
+        chans, counts = np.unique(neg[0], return_counts=True)
+        table = dict(zip(chans.tolist(), counts.tolist()))
+        p = [(table[int(ch)] / n_pos) / table[int(ch)] for ch in pos[0]]    # KeyError as in the reference (utils.py:789-795)
+        off = np.random.choice(n_pos, n_pos - half, replace=False, p=p)
+        valid[pos[0][off], pos[1][off], pos[2][off]] = 0
+        n_pos = half
+    if n_neg + n_pos > max_regions:
+        chans, counts = np.unique(neg[0], return_counts=True)
+        table = dict(zip(chans.tolist(), counts.tolist()))
+        p = [(table[int(ch)] / n_neg) / table[int(ch)] for ch in neg[0]]
+        off = np.random.choice(n_neg, n_neg - n_pos, replace=False, p=p)
+        valid[neg[0][off], neg[1][off], neg[2][off]] = 0
+    return n_pos
+
+
+def select_samples(cls_kept, bg, n_rois):
+    """train.get_selected_samples (train.py:93-129) on the kept RoIs' class indices; host NumPy RNG."""
+    cls_kept = np.asarray(cls_kept)
+    neg = np.where(cls_kept == bg)[0]
+    pos = np.where(cls_kept != bg)[0]
+    if len(pos) < n_rois // 2:
+        sel_pos = pos.tolist()
+    else:
+        sel_pos = np.random.choice(pos, n_rois // 2, replace=False).tolist()
+    if len(neg) > 0:
+        need = n_rois - len(sel_pos)
+        try:
+            sel_neg = np.random.choice(neg, need, replace=False).tolist()
+        except Exception:
+            sel_neg = np.random.choice(neg, need, replace=True).tolist()
+        return sel_pos + sel_neg, len(pos)
+    sel_pos = np.random.choice(pos, len(pos), replace=False).tolist()
+    sel_pos += np.random.choice(pos, n_rois - len(sel_pos), replace=True).tolist()
+    return sel_pos, len(pos)

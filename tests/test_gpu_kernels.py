@@ -1,0 +1,447 @@
+"""HIP kernels (through the C ABI) vs the oracle on identical seeded inputs.
+
+fp32 tolerance for the MFMA GEMM paths: the kernels accumulate in fp32 in k order (v_mfma_f32_32x32x2_f32 is a
+k-ordered fmaf chain), the oracle in fp64 -> relative error ~1e-6*sqrt(K); asserted as
+|gpu - ref| <= 2e-4 * max|ref| + 1e-5 (stated tolerance of this suite).  Integer / index outputs: bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from radnet_hip import lib as L
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test on a machine without a GPU")
+    c = L.Context(0)
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
+    c.check(c.lib.radnet_set_workspace(c.h, ws.data_ptr(), ws.numel()), "ws")
+    c._ws = ws
+    yield c
+    c.close()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def close(gpu, ref, rtol=2e-4, atol=1e-5):
+    ref = np.asarray(ref, dtype=np.float64)
+    gpu = np.asarray(gpu, dtype=np.float64)
+    tol = rtol * np.abs(ref).max() + atol
+    err = np.abs(gpu - ref).max()
+    assert err <= tol, "max err %g > tol %g" % (err, tol)
+
+
+def conv_desc(L, x, w, y, nb, h, wd, c, oh, ow, k, stride, pad, n, ldw, scale=None, shift=None, addend=None, act=0, act_cols=0):
+    d = L.ConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.addend = addend.data_ptr() if addend is not None else None
+    d.nb, d.h, d.w_, d.c, d.oh, d.ow = nb, h, wd, c, oh, ow
+    d.kh = d.kw = k
+    d.stride, d.pad_t, d.pad_l, d.n = stride, pad, pad, n
+    d.ldw, d.ldy, d.ld_add, d.act, d.act_cols = ldw, n, n, act, act_cols
+    return d
+
+
+CONV_CASES = [
+    # nb, h, w, cin, cout, k, stride, pad, relu, residual
+    (1, 19, 23, 64, 64, 1, 1, 0, True, False),
+    (1, 19, 23, 64, 256, 1, 1, 0, True, True),
+    (1, 19, 23, 64, 64, 3, 1, 1, True, False),
+    (1, 21, 30, 256, 128, 1, 2, 0, True, False),
+    (1, 38, 63, 256, 256, 3, 1, 1, True, False),       # stage-4 3x3 at full cfg-2 size (split-K path)
+    (3, 14, 14, 1024, 512, 1, 2, 0, True, False),      # res5a 2a on 3 RoIs
+    (3, 7, 7, 512, 512, 3, 1, 1, True, False),         # res5 3x3 (small M, large K)
+    (2, 9, 11, 128, 96, 3, 1, 1, False, True),         # N not a multiple of the tile
+    (1, 40, 47, 4, 64, 7, 2, 3, True, False),          # stem: 4-channel padded image
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(ctx, case):
+    from radnet_hip import lib as L
+    from oracle import dense
+    nb, h, w, cin, cout, k, stride, pad, relu, residual = case
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rs.standard_normal((nb, h, w, cin)).astype(np.float32)
+    if cin == 4:
+        x[..., 3] = 0
+    wt = (rs.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rs.standard_normal(cout).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    oh = (h + 2 * pad - k) // stride + 1
+    ow = (w + 2 * pad - k) // stride + 1
+    res = rs.standard_normal((nb, oh, ow, cout)).astype(np.float32) if residual else None
+    ref = dense.conv2d(x.astype(np.float64), wt.astype(np.float64), None, stride, (pad, pad, pad, pad)) * scale + b
+    if residual:
+        ref = ref + res
+    if relu:
+        ref = np.maximum(ref, 0)
+    xd, wd, sd, bd = dev(x), dev(wt.reshape(-1, cout)), dev(scale), dev(b)
+    y = torch.full((nb, oh, ow, cout), float("nan"), dtype=torch.float32, device="cuda")
+    rd = dev(res) if residual else None
+    d = conv_desc(L, xd, wd, y, nb, h, w, cin, oh, ow, k, stride, pad, cout, cout, sd, bd, rd, 1 if relu else 0)
+    ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd")
+    ctx.sync()
+    close(y.cpu().numpy(), ref)
+
+
+def test_conv_fwd_sigmoid_head_columns(ctx):
+    from radnet_hip import lib as L
+    from oracle import dense
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((1, 10, 13, 512)).astype(np.float32)
+    wt = np.zeros((512, 64), np.float32)
+    wt[:, :60] = rs.standard_normal((512, 60)) * 0.05
+    b = np.zeros(64, np.float32); b[:60] = rs.standard_normal(60) * 0.1
+    y = torch.zeros(130, 64, device="cuda")
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    d = conv_desc(L, xd, wd, y, 1, 10, 13, 512, 10, 13, 1, 1, 0, 64, 64, None, bd, None, act=2, act_cols=12)
+    ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd")
+    z = x.reshape(130, 512).astype(np.float64) @ wt + b
+    ref = z.copy(); ref[:, :12] = 1 / (1 + np.exp(-z[:, :12]))
+    close(y.cpu().numpy(), ref)
+
+
+DGRAD_CASES = [(2, 7, 7, 512, 512, 3, 1), (2, 7, 7, 512, 2048, 1, 0), (1, 13, 17, 2048, 512, 1, 0), (1, 12, 9, 512, 64, 1, 0), (1, 38, 63, 128, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad_wgrad(ctx, case):
+    """dgrad (with BN scale on dy, residual-path add and the producer's ReLU mask fused) and wgrad + bias colsum."""
+    from radnet_hip import lib as L
+    from oracle import dense
+    nb, h, w, cin, cout, k, pad = case
+    rs = np.random.RandomState(sum(case))
+    x = np.maximum(rs.standard_normal((nb, h, w, cin)), 0).astype(np.float32)          # post-ReLU producer output
+    wt = (rs.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    dy = rs.standard_normal((nb, h, w, cout)).astype(np.float32)
+    gs = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    add = rs.standard_normal((nb, h, w, cin)).astype(np.float32)
+    dx_ref, dw_ref, db_ref = dense.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), (dy * gs).astype(np.float64), 1, (pad,) * 4)
+    dx_ref = (dx_ref + add) * (x > 0)
+    xd, wd, dyd, gsd, addd = dev(x), dev(wt.reshape(-1, cout)), dev(dy), dev(gs), dev(add)
+    dx = torch.full((nb, h, w, cin), float("nan"), device="cuda")
+    dw = torch.full((k * k * cin, cout), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    d = conv_desc(L, xd, wd, dx, nb, h, w, cin, h, w, k, 1, pad, cout, cout)
+    d.dy, d.ld_dy, d.gscale = dyd.data_ptr(), cout, gsd.data_ptr()
+    d.dx, d.ld_dx, d.dx_add, d.ld_dx_add, d.dx_mask, d.ld_dx_mask = dx.data_ptr(), cin, addd.data_ptr(), cin, xd.data_ptr(), cin
+    d.dw, d.dw_accumulate = dw.data_ptr(), 0
+    ctx.check(ctx.lib.radnet_conv_dgrad(ctx.h, C.byref(d)), "dgrad")
+    ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
+    ctx.call("radnet_colsum", dyd, nb * h * w, cout, cout, gsd, db, 0)
+    ctx.sync()
+    close(dx.cpu().numpy(), dx_ref)
+    close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
+    close(db.cpu().numpy(), db_ref)
+    # accumulate mode adds on top
+    ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
+    d.dw_accumulate = 1
+    ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
+    close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
+
+
+def test_wgrad_strided_1x1(ctx):
+    from radnet_hip import lib as L
+    from oracle import dense
+    rs = np.random.RandomState(9)
+    x = rs.standard_normal((3, 14, 14, 1024)).astype(np.float32)
+    wt = np.zeros((1, 1, 1024, 512), np.float32)
+    dy = rs.standard_normal((3, 7, 7, 512)).astype(np.float32)
+    _, dw_ref, _ = dense.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), 2, (0,) * 4, need_dx=False)
+    xd, wd, dyd = dev(x), dev(wt.reshape(1024, 512)), dev(dy)
+    dw = torch.zeros(1024, 512, device="cuda")
+    d = conv_desc(L, xd, wd, dw, 3, 14, 14, 1024, 7, 7, 1, 2, 0, 512, 512)
+    d.dy, d.ld_dy, d.dw, d.dw_accumulate = dyd.data_ptr(), 512, dw.data_ptr(), 0
+    ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
+    close(dw.cpu().numpy(), dw_ref.reshape(1024, 512))
+
+
+def test_conv_rejects_bad_arguments(ctx):
+    from radnet_hip import lib as L
+    x = torch.zeros(1, 8, 8, 48, device="cuda"); w = torch.zeros(48, 64, device="cuda"); y = torch.zeros(64, 64, device="cuda")
+    d = conv_desc(L, x, w, y, 1, 8, 8, 48, 8, 8, 1, 1, 0, 64, 64)          # 48 channels: not a multiple of 32
+    assert ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)) == -3
+    assert b"multiple" in ctx.lib.radnet_last_error(ctx.h)
+    d = conv_desc(L, x, w, y, 1, 8, 8, 64, 8, 8, 1, 1, 0, 62, 62)
+    assert ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)) == -1
+
+
+def test_pools_and_roi_resize(ctx):
+    from oracle import dense
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((2, 21, 30, 64)).astype(np.float32)
+    xd = dev(x)
+    y = torch.zeros(2, 10, 14, 64, device="cuda")
+    ctx.call("radnet_maxpool_fwd", xd, y, 2, 21, 30, 64, 3, 2)
+    assert np.array_equal(y.cpu().numpy(), dense.maxpool_3x3_s2(x))
+    y2 = torch.zeros(2, 10, 15, 64, device="cuda")
+    ctx.call("radnet_maxpool_fwd", xd, y2, 2, 21, 30, 64, 2, 2)
+    assert np.array_equal(y2.cpu().numpy(), dense.maxpool_2x2_s2(x))
+
+    F = rs.standard_normal((1, 38, 63, 1024)).astype(np.float32)
+    rois = np.array([[0, 0, 63, 38], [5, 3, 7, 9], [60, 35, 8, 8], [10, 10, 1, 1], [3.9, 2.2, 20.7, 14.1], [20, 5, 14, 28], [62, 37, 1, 1]], np.float32)
+    for ps in (14, 7):
+        ref = dense.roi_crop_resize(F, rois, ps)
+        out = torch.zeros(len(rois), ps, ps, 1024, device="cuda")
+        ctx.call("radnet_roi_resize_fwd", dev(F), 38, 63, 1024, dev(rois), len(rois), ps, out)
+        close(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    dy = rs.standard_normal((len(rois), 7, 7, 1024)).astype(np.float32)
+    dF = torch.zeros(1, 38, 63, 1024, device="cuda")
+    ctx.call("radnet_roi_resize_bwd", dev(dy), 38, 63, 1024, dev(rois), len(rois), 7, dF)
+    close(dF.cpu().numpy(), dense.roi_crop_resize_bwd(F.shape, rois, 7, dy.astype(np.float64)), rtol=1e-5)
+
+    y5 = rs.standard_normal((5, 49, 2048)).astype(np.float32)
+    feat = torch.zeros(5, 2048, device="cuda")
+    ctx.call("radnet_avgpool_fwd", dev(y5), 5, 49, 2048, feat)
+    close(feat.cpu().numpy(), y5.astype(np.float64).mean(1), rtol=1e-6)
+    dfeat = rs.standard_normal((5, 2048)).astype(np.float32)
+    dx = torch.zeros(5, 49, 2048, device="cuda")
+    ctx.call("radnet_avgpool_bwd_relu", dev(dfeat), dev(y5), 5, 49, 2048, dx)
+    close(dx.cpu().numpy(), (y5 > 0) * dfeat[:, None, :].astype(np.float64) / 49, rtol=1e-6)
+
+
+def test_dense_heads_fwd_bwd(ctx):
+    from oracle import dense
+    rs = np.random.RandomState(12)
+    R, nc, nreg = 20, 7, 24
+    feat = rs.standard_normal((R, 2048)).astype(np.float32)
+    w = np.zeros((2048, 32), np.float32); w[:, :31] = rs.standard_normal((2048, 31)) * 0.02
+    b = np.zeros(32, np.float32); b[:31] = rs.standard_normal(31) * 0.1
+    pc, pr = torch.zeros(R, nc, device="cuda"), torch.zeros(R, nreg, device="cuda")
+    ctx.call("radnet_dense_heads_fwd", dev(feat), R, 2048, dev(w), 32, dev(b), nc, nreg, pc, pr)
+    z = feat.astype(np.float64) @ w + b
+    close(pc.cpu().numpy(), dense.softmax(z[:, :nc]), rtol=1e-5)
+    close(pr.cpu().numpy(), z[:, nc:31], rtol=1e-5)
+    dz = rs.standard_normal((R, 31)).astype(np.float32)
+    dw, db, dfeat = torch.zeros(2048, 32, device="cuda"), torch.zeros(32, device="cuda"), torch.zeros(R, 2048, device="cuda")
+    ctx.call("radnet_dense_heads_bwd", dev(feat), dev(dz), R, 2048, dev(w), 32, 31, dw, db, dfeat)
+    close(dw.cpu().numpy()[:, :31], feat.astype(np.float64).T @ dz, rtol=1e-5)
+    assert np.all(dw.cpu().numpy()[:, 31] == 0)
+    close(db.cpu().numpy()[:31], dz.astype(np.float64).sum(0), rtol=1e-5)
+    close(dfeat.cpu().numpy(), dz.astype(np.float64) @ w[:, :31].T, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rpn_loss(ctx, mode):
+    from oracle import dense
+    rs = np.random.RandomState(13)
+    A, H, W = 12, 38, 63
+    M = H * W
+    valid = (rs.uniform(size=(1, H, W, A)) < 0.02).astype(np.float32)
+    ov = ((rs.uniform(size=(1, H, W, A)) < 0.5) * valid).astype(np.float32)
+    y_cls = np.concatenate([valid, ov], -1)
+    y_regr = np.concatenate([np.repeat(ov, 4, -1), (rs.standard_normal((1, H, W, 4 * A)) * 2).astype(np.float32)], -1)
+    pred = np.zeros((M, 64), np.float32)
+    pred[:, :A] = 1 / (1 + np.exp(-rs.standard_normal((M, A)) * 3))
+    pred[:, A:5 * A] = rs.standard_normal((M, 4 * A))
+    pred[0, 0] = 1.0; pred[1, 1] = 0.0            # saturated sigmoid outputs
+    p = pred[:, :A].reshape(1, H, W, A); r = pred[:, A:5 * A].reshape(1, H, W, 4 * A)
+    lc, dp = dense.rpn_loss_cls(y_cls.astype(np.float64), p.astype(np.float64), A, mode == 0)
+    lr, dr = dense.smooth_l1_masked(y_regr.astype(np.float64), r.astype(np.float64), 4 * A)
+    dz_ref = np.zeros((M, 64))
+    dz_ref[:, :A] = (dp * p * (1 - p)).reshape(M, A)
+    dz_ref[:, A:5 * A] = dr.reshape(M, 4 * A)
+    dz = torch.full((M, 64), float("nan"), device="cuda")
+    losses = torch.zeros(2, device="cuda")
+    scratch = torch.zeros(8, dtype=torch.float64, device="cuda")
+    ctx.call("radnet_rpn_loss", dev(pred), 64, dev(y_cls), dev(y_regr), M, A, mode, dz, 64, losses, scratch)
+    got = losses.cpu().numpy()
+    assert abs(got[0] - lc) <= 2e-5 * abs(lc) + 1e-7 and abs(got[1] - lr) <= 2e-5 * abs(lr) + 1e-7
+    close(dz.cpu().numpy(), dz_ref, rtol=2e-5, atol=1e-9)
+
+
+def test_det_loss(ctx):
+    from oracle import dense
+    rs = np.random.RandomState(14)
+    R, nc, nreg = 20, 7, 24
+    q = dense.softmax(rs.standard_normal((1, R, nc)) * 2).astype(np.float32)
+    pr = rs.standard_normal((1, R, nreg)).astype(np.float32)
+    cls = rs.randint(0, nc, R)
+    Y1 = np.eye(nc, dtype=np.float32)[cls][None]
+    lab = np.zeros((R, nreg), np.float32)
+    for i, c in enumerate(cls):
+        if c != nc - 1:
+            lab[i, 4 * c:4 * c + 4] = 1
+    Y2 = np.concatenate([lab, (rs.standard_normal((R, nreg)) * 2).astype(np.float32) * lab], -1)[None]
+    lc, dq = dense.class_loss_cls(Y1.astype(np.float64), q.astype(np.float64))
+    lr, dr = dense.smooth_l1_masked(Y2.astype(np.float64), pr.astype(np.float64), nreg)
+    q64 = q[0].astype(np.float64)
+    dlog = q64 * (dq[0] - (dq[0] * q64).sum(-1, keepdims=True))
+    dz = torch.zeros(R, nc + nreg, device="cuda"); losses = torch.zeros(3, device="cuda")
+    ctx.call("radnet_det_loss", dev(q[0]), dev(pr[0]), dev(Y1[0]), dev(Y2[0]), R, nc, nreg, dz, losses)
+    got = losses.cpu().numpy()
+    assert abs(got[0] - lc) < 1e-5 * abs(lc) + 1e-7 and abs(got[1] - lr) < 1e-5 * abs(lr) + 1e-7
+    assert abs(got[2] - dense.categorical_accuracy(Y1, q)) < 1e-6
+    close(dz.cpu().numpy()[:, :nc], dlog, rtol=1e-4, atol=1e-8)
+    close(dz.cpu().numpy()[:, nc:], dr[0], rtol=1e-5, atol=1e-9)
+
+
+def test_adam(ctx):
+    from oracle import dense
+    rs = np.random.RandomState(15)
+    n = 4096
+    p = rs.standard_normal(n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    for t in range(1, 5):
+        g = rs.standard_normal(n).astype(np.float32) * 0.1
+        dense.adam_step(p, g, m, v, t, 5e-5)
+        ctx.call("radnet_adam_step", pd, dev(g), md, vd, C.c_int64(n), t, C.c_float(5e-5), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0))
+    assert np.allclose(pd.cpu().numpy(), p, rtol=0, atol=2e-7)
+    assert np.allclose(md.cpu().numpy(), m, rtol=1e-6, atol=1e-9)
+
+
+# ---- fp64 glue: bit-exact against vectors produced by the reference itself -------------------------------------
+def test_rpn_to_roi_golden_bit_exact(ctx):
+    g = load_golden("rpn_to_roi")
+    from faster_rcnn.config import Config
+    for i in range(int(g["n_cases"])):
+        cls, regr = g[f"c{i}_cls"], g[f"c{i}_regr"]
+        _, rows, cols, A = cls.shape
+        Cc = Config(); Cc.anchor_box_scales = [int(v) for v in g[f"c{i}_scales"]]
+        pred = np.zeros((rows * cols, 64), np.float32)
+        pred[:, :A] = cls.reshape(-1, A); pred[:, A:5 * A] = regr.reshape(-1, 4 * A)
+        awh = np.array([[(s * r[0]) / 16, (s * r[1]) / 16] for s in Cc.anchor_box_scales for r in Cc.anchor_box_ratios], dtype=np.float64)
+        mb = int(g[f"c{i}_max"])
+        R = torch.zeros(mb, 4, dtype=torch.int64, device="cuda"); Rp = torch.zeros(mb, device="cuda"); Rn = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(rows * cols * A)), dtype=torch.uint8, device="cuda")
+        rc = ctx.lib.radnet_rpn_to_roi(ctx.h, dev(pred).data_ptr(), 64, rows, cols, A, awh.ctypes.data_as(C.POINTER(C.c_double)), 4.0, 1,
+                                       float(g[f"c{i}_thr"]), mb, R.data_ptr(), Rp.data_ptr(), Rn.data_ptr(), ws.data_ptr())
+        ctx.check(rc, "rpn_to_roi")
+        n = int(Rn.cpu()[0])
+        ref = g[f"c{i}_R"]
+        assert n == ref.shape[0], i
+        assert np.array_equal(R.cpu().numpy()[:n], ref), i
+
+
+def test_nms_golden_bit_exact(ctx):
+    g = load_golden("nms")
+    for i in range(int(g["n_cases"])):
+        boxes = g[f"c{i}_boxes"].astype(np.float64); probs = g[f"c{i}_probs"].astype(np.float32)
+        n = len(boxes)
+        mb = int(g[f"c{i}_max"])
+        idx = torch.zeros(mb, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(n)), dtype=torch.uint8, device="cuda")
+        ctx.call("radnet_nms", dev(boxes), dev(probs), n, C.c_double(float(g[f"c{i}_thr"])), mb, idx, cnt, ws)
+        k = int(cnt.cpu()[0])
+        pick = idx.cpu().numpy()[:k]
+        assert np.array_equal(boxes[pick].astype("int"), g[f"c{i}_out_boxes"]), i
+        assert np.array_equal(g[f"c{i}_probs"][pick], g[f"c{i}_out_probs"]), i
+    # malformed box -> the reference asserts; the kernel reports -1
+    bad = np.array([[0., 0., 5., 5.], [3., 3., 3., 8.]])
+    idx = torch.zeros(10, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(2)), dtype=torch.uint8, device="cuda")
+    ctx.call("radnet_nms", dev(bad), dev(np.array([0.5, 0.6], np.float32)), 2, C.c_double(0.5), 10, idx, cnt, ws)
+    assert int(cnt.cpu()[0]) == -1
+    ctx.call("radnet_nms", None, None, 0, C.c_double(0.5), 10, idx, cnt, ws)
+    assert int(cnt.cpu()[0]) == 0
+
+
+def test_nms_tie_rule(ctx):
+    # equal scores: stable ascending sort walked from the end = higher index first (documented tie rule)
+    boxes = np.array([[0., 0., 10., 10.], [1., 1., 11., 11.], [50., 50., 60., 60.]])
+    probs = np.array([0.5, 0.5, 0.5], np.float32)
+    from oracle import glue
+    rb, _ = glue.greedy_nms(boxes, probs, 0.5, 300)
+    idx = torch.zeros(10, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(3)), dtype=torch.uint8, device="cuda")
+    ctx.call("radnet_nms", dev(boxes), dev(probs), 3, C.c_double(0.5), 10, idx, cnt, ws)
+    k = int(cnt.cpu()[0])
+    assert np.array_equal(boxes[idx.cpu().numpy()[:k]].astype("int"), rb)
+
+
+def test_anchor_targets_golden(ctx):
+    """Labels bit-exact; regression targets bit-exact in the fp32 form the network consumes and within 1 ulp
+    (device log vs NumPy log) in fp64."""
+    from faster_rcnn.config import Config
+    from radnet_hip import engine as E
+    g = load_golden("calc_region_props")
+    for i in range(int(g["n_cases"])):
+        W, H, rw, rh, isz, rseed = (int(v) for v in g[f"c{i}_wh"])
+        Cc = Config(); Cc.img_size = isz
+        gt = g[f"c{i}_gt_boxes"]; isbg = g[f"c{i}_gt_is_bg"].astype(np.int32)
+        ng = len(gt)
+        fw, fh = E.feat_len(rw), E.feat_len(rh)
+        A = 12
+        valid = torch.zeros(A, fh, fw, dtype=torch.uint8, device="cuda"); overlap = torch.zeros_like(valid)
+        regr = torch.zeros(fh, fw, 4 * A, dtype=torch.float64, device="cuda")
+        best = torch.zeros(max(ng, 1), 4, dtype=torch.int32, device="cuda"); nfor = torch.zeros(max(ng, 1), dtype=torch.int32, device="cuda")
+        scratch = torch.zeros(max(ng, 1), dtype=torch.int64, device="cuda")
+        sizes = np.array(Cc.anchor_box_scales, np.float64); ratios = np.array(Cc.anchor_box_ratios, np.float64)
+        gtd = dev(gt) if ng else None; bgd = dev(isbg) if ng else None
+        rc = ctx.lib.radnet_anchor_targets(ctx.h, gtd.data_ptr() if ng else None, bgd.data_ptr() if ng else None, ng, W, H, rw, rh, fw, fh,
+                                           sizes.ctypes.data_as(C.POINTER(C.c_double)), 4, ratios.ctypes.data_as(C.POINTER(C.c_double)), 3, 16.0, 0.7,
+                                           valid.data_ptr(), overlap.data_ptr(), regr.data_ptr(), best.data_ptr(), nfor.data_ptr(), scratch.data_ptr())
+        ctx.check(rc, "anchor_targets")
+        v = valid.cpu().numpy(); o = overlap.cpu().numpy()
+        np.random.seed(rseed)
+        n_pos = E.subsample_valid(v, o)
+        assert n_pos == int(g[f"c{i}_n_pos"]), i
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[f"c{i}_rng_after"]), i
+        ycls_ref, yregr_ref = g[f"c{i}_y_rpn_cls"], g[f"c{i}_y_rpn_regr"]
+        assert np.array_equal(v, ycls_ref[0, :A]), i
+        assert np.array_equal(o, ycls_ref[0, A:]), i
+        if ng:
+            assert np.array_equal(best.cpu().numpy()[:ng], g[f"c{i}_best_anchor"]), i
+        rg = regr.cpu().numpy().transpose(2, 0, 1)
+        ref = yregr_ref[0, 4 * A:]
+        assert np.array_equal(rg.astype(np.float32), ref.astype(np.float32)), i
+        assert np.all(np.abs(rg - ref) <= 4.5e-16 * np.maximum(np.abs(ref), 1e-300)), i
+        # packed fp32 NHWC training tensors (utils.py:475-478)
+        valid.copy_(torch.from_numpy(v))
+        ycls = torch.zeros(fh, fw, 2 * A, device="cuda"); yregr = torch.zeros(fh, fw, 8 * A, device="cuda")
+        ctx.call("radnet_anchor_targets_pack", valid, overlap, regr, fw, fh, A, C.c_double(4.0), ycls, yregr)
+        ref_cls = np.transpose(ycls_ref, (0, 2, 3, 1))[0].astype(np.float32)
+        ref_regr = yregr_ref.copy(); ref_regr[:, 4 * A:] *= 4.0
+        ref_regr = np.transpose(ref_regr, (0, 2, 3, 1))[0].astype(np.float32)
+        assert np.array_equal(ycls.cpu().numpy(), ref_cls), i
+        assert np.array_equal(yregr.cpu().numpy(), ref_regr), i
+
+
+def test_roi_targets_golden(ctx):
+    from faster_rcnn.config import Config
+    from oracle import glue
+    g = load_golden("calc_iou")
+    Cc = Config()
+    std = np.array(Cc.classifier_regr_std, np.float64)
+    for i in range(int(g["n_cases"])):
+        R = g[f"c{i}_R"]; gt = g[f"c{i}_gt_boxes"]; gc = g[f"c{i}_gt_cls"].astype(np.int32)
+        W, H = (int(v) for v in g[f"c{i}_wh"])
+        rw, rh = glue.new_img_size(W, H, Cc.img_size)
+        n = len(R)
+        keep = torch.zeros(n, dtype=torch.uint8, device="cuda"); cls = torch.zeros(n, dtype=torch.int32, device="cuda")
+        box = torch.zeros(n, 4, dtype=torch.int32, device="cuda"); t = torch.zeros(n, 4, dtype=torch.float64, device="cuda")
+        iou = torch.zeros(n, dtype=torch.float64, device="cuda")
+        rc = ctx.lib.radnet_roi_targets(ctx.h, dev(R).data_ptr(), n, dev(gt).data_ptr(), dev(gc).data_ptr(), len(gt), W, H, rw, rh, 16.0, 0.1, 0.5,
+                                        std.ctypes.data_as(C.POINTER(C.c_double)), 6, keep.data_ptr(), cls.data_ptr(), box.data_ptr(), t.data_ptr(), iou.data_ptr())
+        ctx.check(rc, "roi_targets")
+        k = keep.cpu().numpy().astype(bool)
+        X, Y1, Y2 = g[f"c{i}_X"], g[f"c{i}_Y1"], g[f"c{i}_Y2"]
+        assert k.sum() == X.shape[1], i
+        assert np.array_equal(box.cpu().numpy()[k], X[0]), i
+        assert np.array_equal(cls.cpu().numpy()[k], Y1[0].argmax(-1)), i
+        assert np.array_equal(iou.cpu().numpy()[k], g[f"c{i}_ious"]), i
+        # pack every kept RoI and compare the fp32 training tensors
+        sel = np.nonzero(k)[0].astype(np.int32)
+        ro = torch.zeros(len(sel), 4, device="cuda"); y1 = torch.zeros(len(sel), 7, device="cuda"); y2 = torch.zeros(len(sel), 48, device="cuda")
+        ctx.call("radnet_roi_batch_pack", dev(sel), len(sel), cls, box, t, 7, 6, ro, y1, y2)
+        assert np.array_equal(ro.cpu().numpy(), X[0].astype(np.float32))
+        assert np.array_equal(y1.cpu().numpy(), Y1[0].astype(np.float32))
+        got, ref = y2.cpu().numpy(), Y2[0].astype(np.float32)
+        assert np.array_equal(got[:, :24], ref[:, :24])
+        assert np.allclose(got[:, 24:], ref[:, 24:], rtol=2e-7, atol=0)      # log: device vs NumPy, 1 ulp of fp64 -> <= 1 ulp fp32
