@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- train images/sec, ResNet50 Faster R-CNN on synthetic 1000x600 panels (BASELINE.json metric).
+
+One step = one reference training iteration (train.py:278-402) per image: anchor targets, base forward,
+RPN train (fwd+loss+bwd+Adam#1), re-predict, proposals (decode+NMS), RoI labelling + sampling, classifier-head
+train (fwd+loss+bwd+Adam#2) -- nothing skipped (a step whose head phase is skipped aborts the run).
+Inputs (uint8 panels, GT boxes) are resident before the timed region; the panel is uploaded once per step
+from pinned host memory exactly as the reference feeds its model (the PCIe copy is inside the step).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "rock-art-radnet_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+ALGO_GFLOP_PER_IMAGE = 226.4       # minimal train step, base frozen (train.py semantics)
+
+
+def make_batch(rank, per_gpu, H, W):
+    from radnet_hip import synth
+    batch = []
+    for i in range(per_gpu):
+        off = rank * per_gpu + i
+        meta = synth.synthetic_gt(2 + off, n=8, src_w=2 * W, src_h=2 * H)
+        batch.append(dict(img=synth.synthetic_panel(1 + off, H, W), bboxes=meta["bboxes"], width=2 * W, height=2 * H))
+    return batch
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: whole 1000x600 training iterations until ~budget_s seconds are spent (at least 1)."""
+    import copy
+    from faster_rcnn.config import Config
+    from oracle import step as ostep
+    from radnet_hip import synth
+    C = Config()
+    ot = ostep.OracleTrainer(C, copy.deepcopy(synth.synthetic_weights(seed=3)))
+    batch = make_batch(0, 1, 600, 1000)
+    np.random.seed(64)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ot.step(batch[0])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 8:
+            break
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d full train iterations (1000x600, 8 GT, NumPy/BLAS oracle, fp32) in %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--per-gpu-batch", type=int, default=1)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+
+    from faster_rcnn.config import Config
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+
+    C = Config()
+    eng = FasterRCNNEngine(C, device_index=local_rank)
+    eng.set_weights(synth.synthetic_weights(seed=3))
+    ts = TrainStep(eng, world_size=world)
+    batch = make_batch(rank, args.per_gpu_batch, args.height, args.width)
+    np.random.seed(64 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(batch)
+    barrier()
+    skipped0 = ts.skipped_head_steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if ts.skipped_head_steps != skipped0:
+        raise SystemExit("invalid run: %d classifier-head steps were skipped inside the timed region" % (ts.skipped_head_steps - skipped0))
+    losses = ts.losses()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: same step, GEMM launches bracketed by HIP events on the launch stream (not inside `value`)
+    roof = None
+    if args.roofline_steps > 0:
+        eng.ctx.timing(True)
+        eng.ctx.timing_reset()
+        for _ in range(args.roofline_steps):
+            ts.step(batch)
+        torch.cuda.synchronize()
+        per = {}
+        tot_ms = tot_fl = 0.0
+        tot_n = 0
+        for cls, name in ((0, "conv_igemm_fwd"), (1, "conv_igemm_dgrad"), (2, "conv_wgrad")):
+            ms, n, fl = eng.ctx.timing_read(cls)
+            per[name] = {"launches_per_step": n / args.roofline_steps / args.per_gpu_batch, "avg_us": 1e3 * ms / max(n, 1),
+                         "tflops": fl / max(ms, 1e-9) / 1e9}
+            tot_ms += ms; tot_fl += fl; tot_n += n
+        eng.ctx.timing(False)
+        ach = tot_fl / max(tot_ms, 1e-9) / 1e9
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,
+                "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        n_img = world * args.per_gpu_batch * args.steps
+        value = n_img / elapsed
+        out = {
+            "metric": "train images/sec, ResNet50 Faster R-CNN 1000x600",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full train step (RPN + RoiPoolingConv + classifier head + losses + 2x Adam), ResNet50, %dx%d, "
+                                   "batch=%d per GPU, base frozen (train.py)" % (args.width, args.height, args.per_gpu_batch),
+                       "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
+                       "parallelism": "dp%d" % world, "algorithmic_gflop_per_image": ALGO_GFLOP_PER_IMAGE,
+                       "step_tflops_algorithmic": value / world * ALGO_GFLOP_PER_IMAGE / 1e3},
+            "losses": losses,
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,9 +113,9 @@ int radnet_avgpool_bwd_relu(radnet_ctx* ctx, const float* dfeat, const float* y_
 int radnet_dense_heads_fwd(radnet_ctx* ctx, const float* feat, int32_t r, int32_t k, const float* w, int32_t ldw,
                            const float* b, int32_t nc, int32_t nreg, float* out_cls, float* out_regr);
 /* dz: [r][nc+nreg] gradient w.r.t. the pre-softmax logits / regression outputs.
- * Writes dw [k][ldw], db [nc+nreg], dfeat [r][k]. */
+ * Writes (accumulate=0) or adds to (accumulate=1) dw [k][ldw] and db [ldw]; writes dfeat [r][k]. */
 int radnet_dense_heads_bwd(radnet_ctx* ctx, const float* feat, const float* dz, int32_t r, int32_t k, const float* w,
-                           int32_t ldw, int32_t nout, float* dw, float* db, float* dfeat);
+                           int32_t ldw, int32_t nout, float* dw, float* db, float* dfeat, int32_t accumulate);
 
 /* ---- losses (losses.py) ----------------------------------------------------------------------
  * RPN (losses.py:16-66): pred [m][ld_pred] holds the sigmoid class scores in columns [0,A) and the

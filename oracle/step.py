@@ -1,0 +1,73 @@
+"""ORACLE (test infrastructure, not product): one training iteration of the reference (train.py:278-402)
+and the RPN-only / predict-tile paths, composed from oracle/glue.py (pinned by goldens) and oracle/dense.py
+(parity unpinned, torch-cross-checked).  Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg only -- as the checker / the CPU baseline, never as the thing shipped.
+"""
+import numpy as np
+
+from . import dense, glue
+
+
+def feat_size(w, h):
+    return glue.resnet50_feat_len(w), glue.resnet50_feat_len(h)
+
+
+class OracleTrainer:
+    """State of the reference's training script for ResNet50 in train.py mode (base frozen): weights plus
+    the two independent Adam instances (train.py:236-252)."""
+
+    def __init__(self, C, P, lr=5e-5, keras2_bce=True):
+        self.C, self.P = C, P
+        self.A = len(C.anchor_box_scales) * len(C.anchor_box_ratios)
+        self.nc = len(C.class_mapping)
+        self.keras2_bce = keras2_bce
+        self.opt_rpn = dense.AdamState(P, dense.RPN_TRAINABLE, lr)
+        self.opt_head = dense.AdamState(P, dense.head_trainable(self.nc), lr)
+
+    def targets(self, sample):
+        """Data-generator half (utils.py:438-478): anchor targets in the NHWC / scaled layout the model consumes."""
+        C = self.C
+        H, W = sample["img"].shape[:2]
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in sample["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        isbg = np.array([1 if b["class"] == "bg" else 0 for b in sample["bboxes"]])
+        ycls, yregr, _, _ = glue.anchor_targets(C, gt, isbg, sample["width"], sample["height"], W, H, feat_size)
+        return glue.to_train_layout(ycls, yregr, C.std_scaling)
+
+    def step(self, sample, detail=None, override_R=None):
+        """One iteration on one image.  Returns [rpn_cls, rpn_regr, det_cls, det_regr, det_acc] or the first two
+        and None when calc_iou keeps nothing (train.py:378-380).  `detail` (dict) receives intermediates.
+        `override_R`: proposals to label instead of this trainer's own (stage-wise parity checks feed the
+        device's proposals here, because a 1e-7 score difference may legitimately reorder near-tied boxes)."""
+        C, P = self.C, self.P
+        y_cls, y_regr = self.targets(sample)
+        x = dense.preprocess_caffe_bgr(sample["img"])
+        F = dense.base_forward(P, x)                                        # frozen: identical in all three passes
+        l_rpn, g_rpn = dense.rpn_losses_and_grads(P, F, y_cls.astype(np.float32), y_regr.astype(np.float32), self.A, self.keras2_bce)
+        self.opt_rpn.apply(P, g_rpn)                                        # train.py:288
+        p, r, _ = dense.rpn_forward(P, F)                                   # train.py:291 (post-update weights)
+        R = glue.rpn_to_roi(p, r, C, use_regr=True, overlap_thresh=0.7, max_boxes=300)
+        if detail is not None:
+            detail["R_own"] = R
+        if override_R is not None:
+            R = override_R
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in sample["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        gcls = np.array([C.class_mapping[b["class"]] for b in sample["bboxes"]])
+        X2, Y1, Y2, _ = glue.roi_targets(R, gt, gcls, sample["width"], sample["height"], C)
+        if detail is not None:
+            detail.update(F=F, g_rpn=g_rpn, p=p, r=r, R=R, X2=X2, Y1=Y1, Y2=Y2)
+        if X2 is None:
+            return [l_rpn[1], l_rpn[2], None, None, None]
+        sel, _ = glue.select_samples(Y1, C.n_rois)
+        l_det, g_head = dense.head_losses_and_grads(P, F, X2[0, sel].astype(np.float32), Y1[:, sel].astype(np.float32),
+                                                    Y2[:, sel].astype(np.float32), self.nc)
+        self.opt_head.apply(P, g_head)                                      # train.py:393
+        if detail is not None:
+            detail.update(sel=sel, g_head=g_head)
+        return [l_rpn[1], l_rpn[2], l_det[1], l_det[2], l_det[3]]
+
+
+def rpn_only_forward(P, img_bgr_u8):
+    """cfg 1: model_rpn.predict on one image -> (cls, regr, F)."""
+    F = dense.base_forward(P, dense.preprocess_caffe_bgr(img_bgr_u8))
+    p, r, _ = dense.rpn_forward(P, F)
+    return p, r, F

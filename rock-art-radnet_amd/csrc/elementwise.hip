@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) dense_heads_fwd_kernel(const float* __res
 // dw[k][n] = sum_r feat[r][k] dz[r][n];  dfeat[r][k] = sum_n dz[r][n] w[k][n];  db[n] = sum_r dz[r][n]
 __global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dz, int r, int k,
                                                               const float* __restrict__ w, int np, int nout, float* __restrict__ dw,
-                                                              float* __restrict__ db, float* __restrict__ dfeat) {
+                                                              float* __restrict__ db, float* __restrict__ dfeat, int acc) {
   extern __shared__ float sdz[];            // [r][np]
   for (int i = threadIdx.x; i < r * np; i += blockDim.x) {
     int rr = i / np, n = i - rr * np;
@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __res
     for (int n = t; n < np; n += 32) {
       float s = 0.f;
       for (int rr = 0; rr < r; ++rr) s += feat[(long long)rr * k + kk] * sdz[rr * np + n];
-      dw[(long long)kk * np + n] = n < nout ? s : 0.f;
+      const float v = n < nout ? s : 0.f;
+      if (acc) dw[(long long)kk * np + n] += v;
+      else dw[(long long)kk * np + n] = v;
     }
     for (int rr = t; rr < r; rr += 32) {
       float s = 0.f;
@@ -214,7 +216,9 @@ __global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __res
   if (blockIdx.x == 0 && threadIdx.x < np) {
     float s = 0.f;
     for (int rr = 0; rr < r; ++rr) s += sdz[rr * np + threadIdx.x];
-    db[threadIdx.x] = threadIdx.x < nout ? s : 0.f;
+    const float v = threadIdx.x < nout ? s : 0.f;
+    if (acc) db[threadIdx.x] += v;
+    else db[threadIdx.x] = v;
   }
 }
 
@@ -507,11 +511,11 @@ extern "C" int radnet_dense_heads_fwd(radnet_ctx* ctx, const float* feat, int32_
 }
 
 extern "C" int radnet_dense_heads_bwd(radnet_ctx* ctx, const float* feat, const float* dz, int32_t r, int32_t k, const float* w, int32_t ldw,
-                                      int32_t nout, float* dw, float* db, float* dfeat) {
+                                      int32_t nout, float* dw, float* db, float* dfeat, int32_t accumulate) {
   if (!ctx || !feat || !dz || !w || !dw || !db || !dfeat) return RADNET_ERR_ARG;
   const size_t smem = (size_t)r * ldw * sizeof(float);
   if (smem > 64 * 1024) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "dense_heads_bwd: r=%d too large", r);
-  hipLaunchKernelGGL(dense_heads_bwd_kernel, dim3(radnet_cdiv(k, 8)), dim3(256), smem, ctx->stream, feat, dz, r, k, w, ldw, nout, dw, db, dfeat);
+  hipLaunchKernelGGL(dense_heads_bwd_kernel, dim3(radnet_cdiv(k, 8)), dim3(256), smem, ctx->stream, feat, dz, r, k, w, ldw, nout, dw, db, dfeat, accumulate);
   RADNET_CHECK_LAUNCH(ctx, "dense_heads_bwd");
   return RADNET_OK;
 }

@@ -290,9 +290,10 @@ class FasterRCNNEngine:
         d.act_cols = act_cols
         return d, oh, ow
 
-    def _plan_base(self, nb, H, W):
-        """Static launch list of nn_base for (nb,H,W) input: [(kind, payload)], output tensor F."""
-        key = ("base", nb, H, W)
+    def _plan_base(self, nb, H, W, slot=0):
+        """Static launch list of nn_base for (nb,H,W) input: [(kind, payload)], output tensor F.
+        `slot` selects an independent buffer set (one per image of a per-GPU mini-batch)."""
+        key = ("base", nb, H, W, slot)
         if key in self._plans:
             return self._plans[key]
         dev = self.dev
@@ -348,18 +349,28 @@ class FasterRCNNEngine:
                 x, y, nb, hh, ww, c, k, s = p
                 rc = lib.radnet_maxpool_fwd(h, x.data_ptr(), y.data_ptr(), nb, hh, ww, c, k, s)
             elif kind == "colsum":
-                g, m, n, ld, gs, out = p
-                rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, 1)
+                g, m, n, ld, gs, out, acc = p
+                rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, acc)
             else:
                 raise L.RadnetError("unknown op " + kind)
             if rc != 0:
                 self.ctx.check(rc, kind)
 
+    @staticmethod
+    def set_accumulate(ops, flag, dense=None):
+        """First image of a mini-batch overwrites the gradient arena (no memset needed), later ones add."""
+        v = 1 if flag else 0
+        for kind, p in ops:
+            if kind == "wgrad":
+                p.dw_accumulate = v
+            elif kind == "colsum":
+                p[6] = v
+
     # ------------------------------------------------------------------------------------------ forward pieces
-    def upload_image(self, img_bgr_u8, plan=None):
+    def upload_image(self, img_bgr_u8, slot=0):
         """uint8 BGR HWC host image -> preprocessed fp32 NHWC(4) on device (RADNet.py:83-87)."""
         H, W = img_bgr_u8.shape[:2]
-        plan = plan or self._plan_base(1, H, W)
+        plan = self._plan_base(1, H, W, slot)
         raw = torch.from_numpy(np.ascontiguousarray(img_bgr_u8)).to(self.dev)
         self.ctx.call("radnet_preprocess_bgr", raw, H, W, 4, plan["x"])
         return plan
@@ -399,8 +410,8 @@ class FasterRCNNEngine:
         b1 = L.ConvDesc.from_buffer_copy(d1)
         b1.dy, b1.ld_dy, b1.gscale = dh.data_ptr(), 512, None
         b1.dw, b1.dw_accumulate = c1.dweight.data_ptr(), 1
-        bwd = [("wgrad", b2), ("colsum", (dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr())),
-               ("dgrad", b2), ("wgrad", b1), ("colsum", (dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr()))]
+        bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),
+               ("dgrad", b2), ("wgrad", b1), ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
         ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
         plan = dict(fwd=[("conv", d1), ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
@@ -498,19 +509,19 @@ class FasterRCNNEngine:
                 return d
 
             dC = bdesc(B["dc"], cc, g_out, f3, g_b, f2, None, B["b"])
-            bwd += [("wgrad", dC), ("colsum", (g_out.data_ptr(), M, f3, f3, cc.scale.data_ptr(), cc.dbias.data_ptr())), ("dgrad", dC)]
+            bwd += [("wgrad", dC), ("colsum", [g_out.data_ptr(), M, f3, f3, cc.scale.data_ptr(), cc.dbias.data_ptr(), 1]), ("dgrad", dC)]
             dB = bdesc(B["db"], cb, g_b, f2, g_a, f1, None, B["a"])
-            bwd += [("wgrad", dB), ("colsum", (g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr())), ("dgrad", dB)]
+            bwd += [("wgrad", dB), ("colsum", [g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr(), 1]), ("dgrad", dB)]
             if B["first"]:
                 dA = bdesc(B["da"], ca, g_a, f1)
-                bwd += [("wgrad", dA), ("colsum", (g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr()))]
+                bwd += [("wgrad", dA), ("colsum", [g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr(), 1])]
                 cs = self.convs[B["names"][3]]
                 dS = bdesc(B["ds"], cs, g_out, f3)
-                bwd += [("wgrad", dS), ("colsum", (g_out.data_ptr(), M, f3, f3, cs.scale.data_ptr(), cs.dbias.data_ptr()))]
+                bwd += [("wgrad", dS), ("colsum", [g_out.data_ptr(), M, f3, f3, cs.scale.data_ptr(), cs.dbias.data_ptr(), 1])]
             else:
                 g_prev = buf(M, f3)            # grad w.r.t. this block's input = previous block's output (post-ReLU)
                 dA = bdesc(B["da"], ca, g_a, f1, g_prev, f3, g_out, B["x"])
-                bwd += [("wgrad", dA), ("colsum", (g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr())), ("dgrad", dA)]
+                bwd += [("wgrad", dA), ("colsum", [g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr(), 1]), ("dgrad", dA)]
                 g_out = g_prev
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
@@ -524,22 +535,22 @@ class FasterRCNNEngine:
         self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                       hp["pcls"], hp["pregr"])
 
-    def head_backward(self, hp):
+    def head_backward(self, hp, accumulate=False):
         """losses (losses.py:69-95) + gradients of every stage-5 conv and both dense heads into the head grad arena."""
         self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"], self.det_losses)
         self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
-                      self.dense_dw, self.dense_db, hp["dfeat"])
+                      self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
         self._run(hp["bwd"])
 
     # ------------------------------------------------------------------------------------------ targets
-    def anchor_targets(self, gt_boxes, gt_is_bg, width, height, rw, rh):
+    def anchor_targets(self, gt_boxes, gt_is_bg, width, height, rw, rh, slot=0):
         """utils.calc_region_props: device labelling + host RNG subsampling (utils.py:777-813 stays on the host
         NumPy global stream by design) + device packing.  Returns (y_cls, y_regr) fp32 NHWC device tensors,
         best_anchor (host), n_pos.  Raises KeyError exactly where the reference does."""
         fw, fh = feat_len(rw), feat_len(rh)
         A = self.A
-        key = ("atgt", fh, fw)
+        key = ("atgt", fh, fw, slot)
         if key not in self._plans:
             dev = self.dev
             self._plans[key] = dict(valid=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev), overlap=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev),

@@ -51,6 +51,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP runtime as the
+    # tensors whose pointers it receives (two runtimes in one process do not share devices or allocations)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RadnetError("libradnet_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C rock-art-radnet_amd/csrc`). There is no CPU fallback.")
@@ -76,7 +79,7 @@ def load_library():
         "radnet_avgpool_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_avgpool_bwd_relu": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "radnet_dense_heads_fwd": (C.c_int, [vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp]),
-        "radnet_dense_heads_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp]),
+        "radnet_dense_heads_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32]),
         "radnet_rpn_loss": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
         "radnet_det_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32]),

@@ -230,7 +230,7 @@ def test_dense_heads_fwd_bwd(ctx):
     close(pr.cpu().numpy(), z[:, nc:31], rtol=1e-5)
     dz = rs.standard_normal((R, 31)).astype(np.float32)
     dw, db, dfeat = torch.zeros(2048, 32, device="cuda"), torch.zeros(32, device="cuda"), torch.zeros(R, 2048, device="cuda")
-    ctx.call("radnet_dense_heads_bwd", dev(feat), dev(dz), R, 2048, dev(w), 32, 31, dw, db, dfeat)
+    ctx.call("radnet_dense_heads_bwd", dev(feat), dev(dz), R, 2048, dev(w), 32, 31, dw, db, dfeat, 0)
     close(dw.cpu().numpy()[:, :31], feat.astype(np.float64).T @ dz, rtol=1e-5)
     assert np.all(dw.cpu().numpy()[:, 31] == 0)
     close(db.cpu().numpy()[:31], dz.astype(np.float64).sum(0), rtol=1e-5)
