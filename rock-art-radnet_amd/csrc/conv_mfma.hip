@@ -24,6 +24,7 @@
 #include "radnet_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -52,10 +53,23 @@ struct GemmArgs {
   int kt_per_split;      // K tiles per split
   unsigned long long magic_ohow, magic_ow;
   int OHOW;
+  unsigned x_bytes, w_bytes;   // extents for the buffer descriptors
 };
 
 __device__ __forceinline__ int div_magic(int m, unsigned long long magic) {
   return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
+}
+
+// Buffer loads: the 128-bit resource descriptor carries the tensor's byte size, and the hardware returns 0 for
+// any offset beyond it.  Padding taps, rows past M and columns past N are therefore expressed as the offset
+// kOOB instead of a branch: all of a tile's loads issue back to back and are waited for once, at the LDS store.
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // ---- operand staging -----------------------------------------------------------------------------
@@ -70,20 +84,33 @@ __device__ __forceinline__ void store_trans(float* s, int pitch, int row, int kc
   p[3 * pitch] = v.w;
 }
 
+// One 32-deep K tile: 16 MFMA steps of depth 2.  Operand fragments are double-buffered in registers so the
+// ds_reads of step s+1 are in flight while the MFMAs of step s issue (one wave per SIMD has nobody else to
+// hide the LDS latency behind).
 template <int TM, int TN>
 __device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int pitchA, int pitchB, int a_off, int b_off,
                                           f32x16 (&acc)[TM][TN]) {
+  float a[2][TM], b[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a[0][i] = sA[a_off + i * 32];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b[0][j] = sB[b_off + j * 32];
 #pragma unroll
   for (int s = 0; s < BK / 2; ++s) {
-    float a[TM], b[TN];
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < BK / 2) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = sA[(2 * s) * pitchA + a_off + i * 32];
+      for (int i = 0; i < TM; ++i) a[nxt][i] = sA[(2 * s + 2) * pitchA + a_off + i * 32];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = sB[(2 * s) * pitchB + b_off + j * 32];
+      for (int j = 0; j < TN; ++j) b[nxt][j] = sB[(2 * s + 2) * pitchB + b_off + j * 32];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    // pin the order hipcc would otherwise undo: next step's LDS reads first, then this step's MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
   }
 }
 
@@ -143,36 +170,36 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     ci0 = k0 - pos * g.C;
   }
 
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w, g.w_bytes);
   float4 ra[A_ITERS], rb[B_ITERS];
+  float4 rs = make_float4(1, 1, 1, 1);
 
   auto load_tile = [&](int kt) {
-    // ---------------- A: implicit im2col gather
+    // ---------------- A: implicit im2col gather (branch-free: invalid taps load from kOOB -> 0)
     if (SMALLC) {
-      int p = kt * 8 + a_kc;                 // kernel position of this thread's chunk
-      int kh = p / g.KW, kw = p - kh * g.KW;
-      bool pv = p < g.npos;
+      const int p = kt * 8 + a_kc;           // kernel position of this thread's chunk
+      const int kh = p / g.KW, kw = p - kh * g.KW;
+      const bool pv = p < g.npos;
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
-        int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-        bool ok = pv && a_pix[i] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(g.x + (size_t)(a_pix[i] + ih * g.W + iw) * 4) : make_float4(0, 0, 0, 0);
+        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        const bool ok = pv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+        ra[i] = buf_load4(rx, ok ? (unsigned)(a_pix[i] + ih * g.W + iw) * 16u : kOOB);
       }
     } else {
-      int kh = pos / g.KW, kw = pos - kh * g.KW;
-      int ci = ci0 + a_kc * 4;
-      bool kv = (pos * g.C + ci) < g.K;
-      float4 sc = make_float4(1, 1, 1, 1);
-      if (g.in_scale != nullptr && kv) sc = *reinterpret_cast<const float4*>(g.in_scale + ci);
+      const int kh = pos / g.KW, kw = pos - kh * g.KW;
+      const int ci = ci0 + a_kc * 4;
+      const bool kv = (pos * g.C + ci) < g.K;
+      if (g.in_scale != nullptr) {
+        rs = make_float4(0, 0, 0, 0);
+        if (kv) rs = *reinterpret_cast<const float4*>(g.in_scale + ci);
+      }
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
-        int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-        bool ok = kv && a_pix[i] >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (ok) {
-          v = *reinterpret_cast<const float4*>(g.x + (size_t)(a_pix[i] + ih * g.W + iw) * g.C + ci);
-          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-        }
-        ra[i] = v;
+        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        const bool ok = kv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+        ra[i] = buf_load4(rx, ok ? ((unsigned)(a_pix[i] + ih * g.W + iw) * (unsigned)g.C + (unsigned)ci) * 4u : kOOB);
       }
     }
     // ---------------- B
@@ -180,21 +207,21 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       constexpr int CPR = BN / 4;            // float4 chunks per k row
 #pragma unroll
       for (int i = 0; i < B_ITERS; ++i) {
-        int c = tid + NTHREADS * i;
-        int kr = c / CPR, n4 = c - kr * CPR;
-        int k = kt * BK + kr, n = n0 + n4 * 4;
-        bool ok = k < g.K && n < g.N;        // N is a multiple of 4 (launcher checks ldw % 4 == 0)
-        rb[i] = ok ? *reinterpret_cast<const float4*>(g.w + (size_t)k * g.ldw + n) : make_float4(0, 0, 0, 0);
+        const int c = tid + NTHREADS * i;
+        const int kr = c / CPR, n4 = c - kr * CPR;
+        const int k = kt * BK + kr, n = n0 + n4 * 4;
+        const bool ok = (k < g.K) & (n < g.N);  // N is a multiple of 4 (launcher checks)
+        rb[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
       }
     } else {
-      int fpos = g.flip ? (g.npos - 1 - pos) : pos;
-      int co = ci0 + a_kc * 4;              // gathered channel == forward output channel
-      bool kv = (pos * g.C + co) < g.K;
+      const int fpos = g.flip ? (g.npos - 1 - pos) : pos;
+      const int co = ci0 + a_kc * 4;        // gathered channel == forward output channel
+      const bool kv = (pos * g.C + co) < g.K;
 #pragma unroll
       for (int i = 0; i < B_ITERS; ++i) {
-        int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
-        bool ok = kv && n < g.N;
-        rb[i] = ok ? *reinterpret_cast<const float4*>(g.w + ((size_t)fpos * g.cin_fwd + n) * g.ldw + co) : make_float4(0, 0, 0, 0);
+        const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
+        const bool ok = kv & (n < g.N);
+        rb[i] = buf_load4(rw, ok ? (((unsigned)fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)co) * 4u : kOOB);
       }
     }
     if (!SMALLC) {
@@ -207,13 +234,17 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     float* sA = sA0 + buf * BK * PA;
     float* sB = sB0 + buf * BK * PB;
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) store_trans(sA, PA, (tid >> 3) + 32 * i, a_kc, ra[i]);
+    for (int i = 0; i < A_ITERS; ++i) {
+      float4 v = ra[i];
+      v.x *= rs.x; v.y *= rs.y; v.z *= rs.z; v.w *= rs.w;
+      store_trans(sA, PA, (tid >> 3) + 32 * i, a_kc, v);
+    }
     if (BMODE == 0) {
       constexpr int CPR = BN / 4;
 #pragma unroll
       for (int i = 0; i < B_ITERS; ++i) {
-        int c = tid + NTHREADS * i;
-        int kr = c / CPR, n4 = c - kr * CPR;
+        const int c = tid + NTHREADS * i;
+        const int kr = c / CPR, n4 = c - kr * CPR;
         *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = rb[i];
       }
     } else {
@@ -322,6 +353,7 @@ struct WgradArgs {
   int atomic;
   unsigned long long magic_ohow, magic_ow;
   int OHOW;
+  unsigned x_bytes, dy_bytes;
 };
 
 template <int BMK, int BN>
@@ -357,32 +389,26 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   int mt_end = mt_begin + g.mt_per_split;
   if (mt_end > nmt) mt_end = nmt;
 
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(g.dy, g.dy_bytes);
   float4 ra[A_ITERS], rb[B_ITERS];
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (m < g.M && a_kv) {
-        int img = div_magic(m, g.magic_ohow);
-        int rem = m - img * g.OHOW;
-        int oh = div_magic(rem, g.magic_ow);
-        int ow = rem - oh * g.OW;
-        int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
-        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-          v = *reinterpret_cast<const float4*>(g.x + ((size_t)(img * g.H + ih) * g.W + iw) * g.C + cbase + a_k4 * 4);
-      }
-      ra[i] = v;
+      const int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
+      const int img = div_magic(m, g.magic_ohow);
+      const int rem = m - img * g.OHOW;
+      const int oh = div_magic(rem, g.magic_ow);
+      const int ow = rem - oh * g.OW;
+      const int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+      const bool ok = (m < g.M) & a_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+      ra[i] = buf_load4(rx, ok ? (((unsigned)(img * g.H + ih) * (unsigned)g.W + (unsigned)iw) * (unsigned)g.C + (unsigned)(cbase + a_k4 * 4)) * 4u : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      int m = mt * BK + b_mr + (NTHREADS / CPRB) * i;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (m < g.M && b_nv) {
-        v = *reinterpret_cast<const float4*>(g.dy + (size_t)m * g.ld_dy + n0 + b_n4 * 4);
-        v.x *= gs.x; v.y *= gs.y; v.z *= gs.z; v.w *= gs.w;
-      }
-      rb[i] = v;
+      const int m = mt * BK + b_mr + (NTHREADS / CPRB) * i;
+      const bool ok = (m < g.M) & b_nv;
+      rb[i] = buf_load4(rdy, ok ? ((unsigned)m * (unsigned)g.ld_dy + (unsigned)(n0 + b_n4 * 4)) * 4u : kOOB);
     }
   };
   auto store_tile = [&](int buf) {
@@ -392,8 +418,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
     for (int i = 0; i < A_ITERS; ++i)
       *reinterpret_cast<float4*>(sA + (a_mr + (NTHREADS / CPRA) * i) * PA + a_k4 * 4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i)
-      *reinterpret_cast<float4*>(sB + (b_mr + (NTHREADS / CPRB) * i) * PB + b_n4 * 4) = rb[i];
+    for (int i = 0; i < B_ITERS; ++i) {
+      float4 v = rb[i];
+      v.x *= gs.x; v.y *= gs.y; v.z *= gs.z; v.w *= gs.w;
+      *reinterpret_cast<float4*>(sB + (b_mr + (NTHREADS / CPRB) * i) * PB + b_n4 * 4) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -497,6 +526,13 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   if (!smallc && (g.C % BK) != 0) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: channels %d not a multiple of %d (pad, or use c=4)", g.C, BK);
   g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
   g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  {
+    const uint64_t xb = (uint64_t)(g.M / g.OHOW) * g.H * g.W * g.C * 4ull;      // images * H * W * C floats
+    const uint64_t wb = (bmode == 0) ? (uint64_t)g.K * g.ldw * 4ull : (uint64_t)g.npos * g.cin_fwd * g.ldw * 4ull;
+    if (xb >= (1ull << 31) || wb >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: tensor larger than 2 GiB");
+    g.x_bytes = (unsigned)xb;
+    g.w_bytes = (unsigned)wb;
+  }
   TileChoice tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
   if (tc.splits > 1) {
     const uint64_t need = (uint64_t)tc.splits * g.M * g.N * sizeof(float);
@@ -577,6 +613,12 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   if ((g.N & 3) || (g.ld_dy & 3) || (g.ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: n, ld_dy, ldw must be multiples of 4");
   g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
   g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  {
+    const uint64_t xb = (uint64_t)d->nb * d->h * d->w_ * d->c * 4ull, db = (uint64_t)g.M * g.ld_dy * 4ull;
+    if (xb >= (1ull << 31) || db >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: tensor larger than 2 GiB");
+    g.x_bytes = (unsigned)xb;
+    g.dy_bytes = (unsigned)db;
+  }
   int bmk = (d->c % 128 == 0) ? 128 : 64;
   if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
   int bn = g.N > 64 ? 128 : 64;
