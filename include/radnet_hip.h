@@ -40,6 +40,12 @@ int radnet_sync(radnet_ctx* ctx);
 int radnet_version(void);
 /* Scratch the library may use for split-K partial sums (caller-owned, >= bytes). */
 int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);
+/* Autotuning of the conv GEMM launch shape.  While enabled, the FIRST conv_fwd / conv_dgrad / conv_wgrad call of
+ * each problem shape times every (output tile, split-K) candidate on the ctx stream (synchronising it) and caches
+ * the fastest; later calls of that shape reuse the choice.  Shapes are static per image size, so a warm-up step
+ * tunes the whole layer program.  radnet_tuned_shapes() returns the number of cached shapes. */
+int radnet_set_autotune(radnet_ctx* ctx, int enable);
+int radnet_tuned_shapes(radnet_ctx* ctx);
 /* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
  * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
  * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd,1 dgrad,2 wgrad). */
@@ -172,7 +178,9 @@ int radnet_anchor_targets_pack(radnet_ctx* ctx, const uint8_t* valid, const uint
 int radnet_roi_targets(radnet_ctx* ctx, const int64_t* rois, int32_t n, const double* gt, const int32_t* gt_cls, int32_t g,
                        int32_t width, int32_t height, int32_t rw, int32_t rh, double rpn_stride, double min_overlap,
                        double max_overlap, const double* regr_std_host4, int32_t bg_class, uint8_t* keep, int32_t* cls,
-                       int32_t* box, double* t, double* iou);
+                       int32_t* box, double* t, double* iou, const int32_t* n_dev);
+/* ^ cls is -1 for dropped RoIs.  n_dev (optional device int32): only the first min(*n_dev, n) rows are labelled,
+ *   so the NMS count never has to travel to the host between the two kernels. */
 /* Build the detector batch for `r` selected RoIs: rois_out fp32 [r][4], y1 [r][nc], y2 [r][8(nc-1)]. */
 int radnet_roi_batch_pack(radnet_ctx* ctx, const int32_t* sel, int32_t r, const int32_t* cls, const int32_t* box,
                           const double* t, int32_t nc, int32_t bg_class, float* rois_out, float* y1, float* y2);

@@ -26,6 +26,8 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
     (void)hipEventDestroy(ctx->pend0[i]);
     (void)hipEventDestroy(ctx->pend1[i]);
   }
+  if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
+  if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
   delete ctx;
 }
 
@@ -36,6 +38,14 @@ extern "C" int radnet_sync(radnet_ctx* ctx) {
   RADNET_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RADNET_OK;
 }
+
+extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
+  if (!ctx) return RADNET_ERR_ARG;
+  ctx->autotune = enable ? 1 : 0;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_tuned_shapes(radnet_ctx* ctx) { return ctx ? (int)ctx->tuned.size() : -1; }
 
 extern "C" int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes) {
   if (!ctx) return RADNET_ERR_ARG;

@@ -533,29 +533,60 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.x_bytes = (unsigned)xb;
     g.w_bytes = (unsigned)wb;
   }
-  TileChoice tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
-  if (tc.splits > 1) {
-    const uint64_t need = (uint64_t)tc.splits * g.M * g.N * sizeof(float);
-    if (need > ctx->ws_bytes) tc.splits = 1;
-  }
   const int nk = radnet_cdiv(g.K, BK);
-  g.kt_per_split = radnet_cdiv(nk, tc.splits);
-  g.partial = tc.splits > 1 ? (float*)ctx->ws : nullptr;
-  radnet_timing_begin(ctx);
-  if (bmode == 0) {
-    if (smallc) launch_igemm<0, true>(ctx->stream, g, tc);
-    else launch_igemm<0, false>(ctx->stream, g, tc);
+  auto fits = [&](const TileChoice& t) {
+    if (t.splits > 1 && (uint64_t)t.splits * g.M * g.N * sizeof(float) > ctx->ws_bytes) return false;
+    if (t.splits > 1 && radnet_cdiv(nk, radnet_cdiv(nk, t.splits)) != t.splits) return false;   // no empty split
+    return true;
+  };
+  auto launch = [&](const TileChoice& t) -> int {
+    g.kt_per_split = radnet_cdiv(nk, t.splits);
+    g.partial = t.splits > 1 ? (float*)ctx->ws : nullptr;
+    if (bmode == 0) {
+      if (smallc) launch_igemm<0, true>(ctx->stream, g, t);
+      else launch_igemm<0, false>(ctx->stream, g, t);
+    } else {
+      launch_igemm<1, false>(ctx->stream, g, t);
+    }
+    RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
+    if (t.splits > 1) {
+      const long long total = (long long)g.M * (g.N >> 2);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g, t.splits);
+      RADNET_CHECK_LAUNCH(ctx, "splitk_epilogue");
+    }
+    return RADNET_OK;
+  };
+  // tile / split-K choice: measured once per problem shape when autotuning is on, else the cost model
+  const radnet_shape_key key{cls == 1 ? 1 : 0, g.M, g.N, g.K, g.C, g.npos, g.stride};
+  TileChoice tc{64, 64, 1};
+  auto it = ctx->tuned.find(key);
+  if (it != ctx->tuned.end()) {
+    tc = TileChoice{it->second.a, it->second.b, it->second.splits};
+  } else if (ctx->autotune) {
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const int splits[] = {1, 2, 3, 4, 5, 6, 8, 12};
+    float best = 1e30f;
+    for (int c = 0; c < 4; ++c) {
+      if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
+      for (int s : splits) {
+        TileChoice t{cand[c][0], cand[c][1], s};
+        if ((s > 1 && nk / s < 4) || !fits(t)) continue;
+        float ms = 0.f;
+        int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
+        if (rc != RADNET_OK) return rc;
+        if (ms < best) { best = ms; tc = t; }
+      }
+    }
+    ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best};
   } else {
-    launch_igemm<1, false>(ctx->stream, g, tc);
+    tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
+    if (!fits(tc)) tc.splits = 1;
   }
-  RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
-  if (tc.splits > 1) {
-    const long long total = (long long)g.M * (g.N >> 2);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g, tc.splits);
-    RADNET_CHECK_LAUNCH(ctx, "splitk_epilogue");
-  }
+  radnet_timing_begin(ctx);
+  int rc = launch(tc);
+  if (rc != RADNET_OK) return rc;
   radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K);
   return RADNET_OK;
 }
@@ -619,30 +650,62 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
     g.x_bytes = (unsigned)xb;
     g.dy_bytes = (unsigned)db;
   }
-  int bmk = (d->c % 128 == 0) ? 128 : 64;
-  if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
-  int bn = g.N > 64 ? 128 : 64;
-  long long tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
-  if (tiles < kNumCU && bmk == 128 && bn == 128) {
-    // more, smaller tiles first (no atomics needed)
-    bn = 64;
-    tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
-  }
+  if (d->c % 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
   const int nmt = radnet_cdiv(g.M, BK);
-  int splits = 1;
-  while (tiles * splits < 2 * kNumCU && nmt / (splits * 2) >= 4 && splits < 16) splits *= 2;
-  g.mt_per_split = radnet_cdiv(nmt, splits);
-  g.atomic = (splits > 1 || d->dw_accumulate) ? 1 : 0;
-  if (splits > 1 && !d->dw_accumulate) {
-    // atomics need a zeroed destination
-    RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
+  auto launch = [&](int bmk, int bn, int splits) -> int {
+    g.mt_per_split = radnet_cdiv(nmt, splits);
+    g.atomic = (splits > 1 || d->dw_accumulate) ? 1 : 0;
+    if (splits > 1 && !d->dw_accumulate)      // atomics need a zeroed destination
+      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
+    dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits), block(NTHREADS);
+    if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
+    else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
+    else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, ctx->stream, g);
+    RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
+    return RADNET_OK;
+  };
+  int bmk = (d->c % 128 == 0) ? 128 : 64, bn = g.N > 64 ? 128 : 64, splits = 1;
+  const radnet_shape_key key{2 + (d->dw_accumulate ? 1 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
+  auto it = ctx->tuned.find(key);
+  if (it != ctx->tuned.end()) {
+    bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
+  } else if (ctx->autotune && !d->dw_accumulate) {
+    float best = 1e30f;
+    for (int cb = 128; cb >= 64; cb -= 64) {
+      if (d->c % cb) continue;
+      for (int cn = 128; cn >= 64; cn -= 64) {
+        if (cn > 64 && g.N <= 64) continue;
+        for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
+          if (s > 1 && (nmt / s < 2 || radnet_cdiv(nmt, radnet_cdiv(nmt, s)) != s)) continue;
+          float ms = 0.f;
+          int rc = radnet_time_launches(ctx, [&]() { return launch(cb, cn, s); }, 3, &ms);
+          if (rc != RADNET_OK) return rc;
+          if (ms < best) { best = ms; bmk = cb; bn = cn; splits = s; }
+        }
+      }
+    }
+    ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best};
+  } else {
+    // accumulate mode reuses the overwrite-mode measurement when there is one
+    const radnet_shape_key k0{2, g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
+    auto it0 = ctx->tuned.find(k0);
+    if (it0 != ctx->tuned.end()) {
+      bmk = it0->second.a; bn = it0->second.b; splits = it0->second.splits;
+    } else {
+      long long tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
+      if (tiles < kNumCU && bmk == 128 && bn == 128) {
+        bn = 64;
+        tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);
+      }
+      while (tiles * splits < 2 * kNumCU && nmt / (splits * 2) >= 4 && splits < 16) splits *= 2;
+    }
   }
-  dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits), block(NTHREADS);
   radnet_timing_begin(ctx);
-  if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
-  else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
-  else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, ctx->stream, g);
+  {
+    int rc = launch(bmk, bn, splits);
+    if (rc != RADNET_OK) return rc;
+  }
   RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
   radnet_timing_end(ctx, 2, 2.0 * g.M * g.N * g.K);
   return RADNET_OK;

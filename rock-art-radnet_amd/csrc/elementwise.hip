@@ -303,10 +303,13 @@ __global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restr
       s3 += mask * sl;
     }
   }
+  // wave shuffle -> LDS across the 4 waves -> ONE atomic per sum per block (contended fp64 atomics are ~10 ns each)
+  __shared__ double red[4][4];
   s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(scratch + 0, s0); atomicAdd(scratch + 1, s1); atomicAdd(scratch + 2, s2); atomicAdd(scratch + 3, s3);
-  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(scratch + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256) rpn_loss_grad_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,
@@ -549,7 +552,7 @@ extern "C" int radnet_rpn_loss(radnet_ctx* ctx, const float* pred, int32_t ld_pr
   if (!ctx || !pred || !y_cls || !y_regr || !dz || !losses || !scratch8) return RADNET_ERR_ARG;
   if (ld_pred < 5 * a || ld_dz < 5 * a) RADNET_FAIL(ctx, RADNET_ERR_ARG, "rpn_loss: leading dims too small");
   RADNET_CHECK_HIP(ctx, hipMemsetAsync(scratch8, 0, 8 * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(rpn_loss_sums_kernel, dim3(grid_for((long long)m * 5 * a, 256, 1024)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
+  hipLaunchKernelGGL(rpn_loss_sums_kernel, dim3(grid_for((long long)m * 5 * a, 256, 256)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
                      y_regr, m, a, bce_mode, scratch8);
   RADNET_CHECK_LAUNCH(ctx, "rpn_loss_sums");
   hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(grid_for((long long)m * ld_dz, 256, 2048)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,

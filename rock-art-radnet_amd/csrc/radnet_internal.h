@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <tuple>
+
 #include "radnet_hip.h"
 
 struct radnet_timing_slot {
@@ -13,7 +16,22 @@ struct radnet_timing_slot {
   int64_t launches = 0;
 };
 
+// Measured tile / split choice per GEMM problem shape (filled by the launchers when autotuning is on).
+struct radnet_shape_key {
+  int kind, m, n, k, c, npos, stride;
+  bool operator<(const radnet_shape_key& o) const {
+    return std::tie(kind, m, n, k, c, npos, stride) < std::tie(o.kind, o.m, o.n, o.k, o.c, o.npos, o.stride);
+  }
+};
+struct radnet_tuned {
+  int a, b, splits;
+  float ms;
+};
+
 struct radnet_ctx {
+  int autotune = 0;
+  std::map<radnet_shape_key, radnet_tuned> tuned;
+  hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   char err[512] = {0};
@@ -56,6 +74,28 @@ void radnet_timing_begin(radnet_ctx* ctx);
 void radnet_timing_end(radnet_ctx* ctx, int cls, double flops);
 
 static inline int radnet_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Autotune helper: one warm-up launch, then `iters` launches bracketed by HIP events on the ctx stream.
+template <typename F>
+static inline int radnet_time_launches(radnet_ctx* ctx, F&& launch, int iters, float* ms_out) {
+  if (!ctx->tune_ev0) {
+    RADNET_CHECK_HIP(ctx, hipEventCreate(&ctx->tune_ev0));
+    RADNET_CHECK_HIP(ctx, hipEventCreate(&ctx->tune_ev1));
+  }
+  int rc = launch();
+  if (rc != RADNET_OK) return rc;
+  RADNET_CHECK_HIP(ctx, hipEventRecord(ctx->tune_ev0, ctx->stream));
+  for (int i = 0; i < iters; ++i) {
+    rc = launch();
+    if (rc != RADNET_OK) return rc;
+  }
+  RADNET_CHECK_HIP(ctx, hipEventRecord(ctx->tune_ev1, ctx->stream));
+  RADNET_CHECK_HIP(ctx, hipEventSynchronize(ctx->tune_ev1));
+  float ms = 0.f;
+  RADNET_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->tune_ev0, ctx->tune_ev1));
+  *ms_out = ms / iters;
+  return RADNET_OK;
+}
 
 // exact floor(m / d) for m, d < 2^20 as (m * magic) >> 40  (m*d < 2^40, see conv_mfma.hip)
 static inline uint64_t radnet_div_magic(uint32_t d) { return ((1ull << 40) + d - 1) / d; }

@@ -172,6 +172,7 @@ struct RoiArgs {
   const long long* rois;
   const double* gt;
   const int* gt_cls;
+  const int* n_dev;
   int n, g, width, height, rw, rh, bg;
   double stride, min_ov, max_ov;
   double std[4];
@@ -181,6 +182,11 @@ __global__ void __launch_bounds__(256) roi_targets_kernel(RoiArgs g, uint8_t* __
                                                           double* __restrict__ t, double* __restrict__ iou_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.n) return;
+  if (g.n_dev != nullptr && i >= *g.n_dev) {      // rows beyond the device-side proposal count: not kept
+    keep[i] = 0;
+    cls[i] = -1;
+    return;
+  }
   const double x1 = (double)g.rois[4 * i], y1 = (double)g.rois[4 * i + 1], x2 = (double)g.rois[4 * i + 2], y2 = (double)g.rois[4 * i + 3];
   double best = 0.0;
   int bk = -1;
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(256) roi_targets_kernel(RoiArgs g, uint8_t* __
     }
   }
   keep[i] = kp ? 1 : 0;
-  cls[i] = c;
+  cls[i] = kp ? c : -1;                           // -1 = dropped (IoU < min_overlap): one array tells the host everything
   box[4 * i + 0] = (int)x1; box[4 * i + 1] = (int)y1; box[4 * i + 2] = (int)w; box[4 * i + 3] = (int)h;
   for (int q = 0; q < 4; ++q) t[4 * i + q] = tt[q];
   iou_out[i] = best;
@@ -278,11 +284,12 @@ extern "C" int radnet_anchor_targets_pack(radnet_ctx* ctx, const uint8_t* valid,
 extern "C" int radnet_roi_targets(radnet_ctx* ctx, const int64_t* rois, int32_t n, const double* gt, const int32_t* gt_cls, int32_t g,
                                   int32_t width, int32_t height, int32_t rw, int32_t rh, double rpn_stride, double min_overlap,
                                   double max_overlap, const double* regr_std_host4, int32_t bg_class, uint8_t* keep, int32_t* cls,
-                                  int32_t* box, double* t, double* iou) {
+                                  int32_t* box, double* t, double* iou, const int32_t* n_dev) {
   if (!ctx || !rois || !keep || !cls || !box || !t || !iou || !regr_std_host4) return RADNET_ERR_ARG;
   if (n <= 0) return RADNET_OK;
   if (g > 0 && (!gt || !gt_cls)) return RADNET_ERR_ARG;
   RoiArgs a{};
+  a.n_dev = n_dev;
   a.rois = (const long long*)rois; a.gt = gt; a.gt_cls = gt_cls; a.n = n; a.g = g; a.width = width; a.height = height; a.rw = rw; a.rh = rh;
   a.bg = bg_class; a.stride = rpn_stride; a.min_ov = min_overlap; a.max_ov = max_overlap;
   for (int i = 0; i < 4; ++i) a.std[i] = regr_std_host4[i];

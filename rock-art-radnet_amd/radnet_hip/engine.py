@@ -92,7 +92,7 @@ class FasterRCNNEngine:
     """ResNet50 Faster R-CNN on one MI355X.  `mode`: 'train' = train.py trainability (whole base frozen);
     inference uses the same object."""
 
-    def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5):
+    def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5, autotune=True):
         if C_cfg.network != "resnet50":
             raise L.RadnetError("engine: network %r not built yet (resnet50 only)" % (C_cfg.network,))
         self.C = C_cfg
@@ -113,6 +113,7 @@ class FasterRCNNEngine:
         self._plans = {}
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
+        self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
         self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)
@@ -425,10 +426,10 @@ class FasterRCNNEngine:
         self._run(rp["fwd"])
         return rp
 
-    def rpn_backward(self, rp, y_cls, y_regr):
+    def rpn_backward(self, rp, y_cls, y_regr, loss_out=None):
         """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
         self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,
-                      self.rpn_losses, self.loss_scratch)
+                      self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
         self._run(rp["bwd"])
 
     def adam(self, arena, grad_scale=1.0):
@@ -535,19 +536,28 @@ class FasterRCNNEngine:
         self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                       hp["pcls"], hp["pregr"])
 
-    def head_backward(self, hp, accumulate=False):
+    def head_backward(self, hp, accumulate=False, loss_out=None):
         """losses (losses.py:69-95) + gradients of every stage-5 conv and both dense heads into the head grad arena."""
-        self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"], self.det_losses)
+        self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
+                      self.det_losses if loss_out is None else loss_out)
         self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
                       self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
         self._run(hp["bwd"])
 
     # ------------------------------------------------------------------------------------------ targets
-    def anchor_targets(self, gt_boxes, gt_is_bg, width, height, rw, rh, slot=0):
-        """utils.calc_region_props: device labelling + host RNG subsampling (utils.py:777-813 stays on the host
-        NumPy global stream by design) + device packing.  Returns (y_cls, y_regr) fp32 NHWC device tensors,
-        best_anchor (host), n_pos.  Raises KeyError exactly where the reference does."""
+    def upload_gt(self, gt_boxes, gt_is_bg, gt_cls):
+        """GT boxes [g][4] fp64 (x1,y1,x2,y2 source px), is-bg flags and class indices -> device (once per sample)."""
+        g = len(gt_boxes)
+        dev = self.dev
+        return dict(g=g,
+                    boxes=torch.from_numpy(np.ascontiguousarray(gt_boxes, dtype=np.float64).reshape(-1, 4)).to(dev) if g else None,
+                    isbg=torch.from_numpy(np.ascontiguousarray(gt_is_bg, dtype=np.int32)).to(dev) if g else None,
+                    cls=torch.from_numpy(np.ascontiguousarray(gt_cls, dtype=np.int32)).to(dev) if g else None)
+
+    def anchor_targets_launch(self, gt, width, height, rw, rh, slot=0):
+        """Device half of utils.calc_region_props (utils.py:585-766) + ASYNC copy of the valid/overlap maps to pinned
+        host memory.  The caller may enqueue unrelated GPU work (base forward) before anchor_targets_finish()."""
         fw, fh = feat_len(rw), feat_len(rh)
         A = self.A
         key = ("atgt", fh, fw, slot)
@@ -556,51 +566,87 @@ class FasterRCNNEngine:
             self._plans[key] = dict(valid=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev), overlap=torch.zeros(A, fh, fw, dtype=torch.uint8, device=dev),
                                     regr=torch.zeros(fh, fw, 4 * A, dtype=torch.float64, device=dev),
                                     ycls=torch.zeros(fh, fw, 2 * A, dtype=torch.float32, device=dev),
-                                    yregr=torch.zeros(fh, fw, 8 * A, dtype=torch.float32, device=dev))
+                                    yregr=torch.zeros(fh, fw, 8 * A, dtype=torch.float32, device=dev),
+                                    h_valid=torch.zeros(A, fh, fw, dtype=torch.uint8).pin_memory(), h_overlap=torch.zeros(A, fh, fw, dtype=torch.uint8).pin_memory(),
+                                    best=torch.zeros(1024, 4, dtype=torch.int32, device=dev), nfor=torch.zeros(1024, dtype=torch.int32, device=dev),
+                                    scratch=torch.zeros(1024, dtype=torch.int64, device=dev), event=torch.cuda.Event(), fw=fw, fh=fh)
         P = self._plans[key]
-        g = len(gt_boxes)
-        gt = torch.from_numpy(np.ascontiguousarray(gt_boxes, dtype=np.float64).reshape(-1, 4)).to(self.dev) if g else None
-        isbg = torch.from_numpy(np.ascontiguousarray(gt_is_bg, dtype=np.int32)).to(self.dev) if g else None
-        best = torch.zeros(max(g, 1), 4, dtype=torch.int32, device=self.dev)
-        nfor = torch.zeros(max(g, 1), dtype=torch.int32, device=self.dev)
-        scratch = torch.zeros(max(g, 1), dtype=torch.int64, device=self.dev)
-        rc = self.lib.radnet_anchor_targets(self.ctx.h, gt.data_ptr() if g else None, isbg.data_ptr() if g else None, g, int(width), int(height),
+        g = gt["g"]
+        rc = self.lib.radnet_anchor_targets(self.ctx.h, gt["boxes"].data_ptr() if g else None, gt["isbg"].data_ptr() if g else None, g, int(width), int(height),
                                             int(rw), int(rh), fw, fh, self.anchor_sizes.ctypes.data_as(C.POINTER(C.c_double)), len(self.anchor_sizes),
                                             self.anchor_ratios.ctypes.data_as(C.POINTER(C.c_double)), len(self.anchor_ratios), float(self.C.rpn_stride),
                                             float(self.C.rpn_max_overlap), P["valid"].data_ptr(), P["overlap"].data_ptr(), P["regr"].data_ptr(),
-                                            best.data_ptr(), nfor.data_ptr(), scratch.data_ptr())
+                                            P["best"].data_ptr(), P["nfor"].data_ptr(), P["scratch"].data_ptr())
         self.ctx.check(rc, "radnet_anchor_targets")
-        valid = P["valid"].cpu().numpy()          # D2H (syncs): 2 x A*fh*fw bytes
-        overlap = P["overlap"].cpu().numpy()
-        n_pos = subsample_valid(valid, overlap)
-        P["valid"].copy_(torch.from_numpy(valid))
-        self.ctx.call("radnet_anchor_targets_pack", P["valid"], P["overlap"], P["regr"], fw, fh, A, C.c_double(float(self.C.std_scaling)),
-                      P["ycls"], P["yregr"])
-        best_h = best.cpu().numpy()[:g].astype(np.int64) if g else np.zeros((0, 4), np.int64)
-        return P["ycls"], P["yregr"], best_h, n_pos
+        P["h_valid"].copy_(P["valid"], non_blocking=True)
+        P["h_overlap"].copy_(P["overlap"], non_blocking=True)
+        P["event"].record()
+        P["g"] = g
+        return P
 
-    def roi_targets(self, R_dev, n, gt_boxes, gt_cls, width, height, rw, rh):
-        """rpn.calc_iou on device.  Returns host (keep u8 [n], cls i32 [n]) and device (box, t) for packing."""
+    def anchor_targets_finish(self, P):
+        """Host half (utils.py:777-813: the RNG-driven subsampling stays on NumPy's global stream by design), then the
+        device packs the fp32 NHWC training tensors.  Raises KeyError exactly where the reference does."""
+        P["event"].synchronize()
+        valid = P["h_valid"].numpy()
+        n_pos = subsample_valid(valid, P["h_overlap"].numpy())
+        P["valid"].copy_(P["h_valid"], non_blocking=True)
+        self.ctx.call("radnet_anchor_targets_pack", P["valid"], P["overlap"], P["regr"], P["fw"], P["fh"], self.A, C.c_double(float(self.C.std_scaling)),
+                      P["ycls"], P["yregr"])
+        return P["ycls"], P["yregr"], n_pos
+
+    def anchor_targets(self, gt_boxes, gt_is_bg, width, height, rw, rh, slot=0):
+        """utils.calc_region_props end to end: (y_cls, y_regr) fp32 NHWC device tensors, best_anchor (host), n_pos."""
+        gt = self.upload_gt(gt_boxes, gt_is_bg, np.zeros(len(gt_boxes), np.int32))
+        P = self.anchor_targets_launch(gt, width, height, rw, rh, slot)
+        ycls, yregr, n_pos = self.anchor_targets_finish(P)
+        g = gt["g"]
+        best_h = P["best"][:g].cpu().numpy().astype(np.int64) if g else np.zeros((0, 4), np.int64)
+        return ycls, yregr, best_h, n_pos
+
+    def roi_targets(self, R_dev, n_dev, gt, width, height, rw, rh, n_max=300):
+        """rpn.calc_iou on device for the first min(*n_dev, n_max) proposals; one pinned D2H brings back the per-RoI
+        class code (-1 = dropped).  Returns (plan, cls host int32 [n], n)."""
         dev = self.dev
         key = ("rtgt",)
         if key not in self._plans:
             self._plans[key] = dict(keep=torch.zeros(1024, dtype=torch.uint8, device=dev), cls=torch.zeros(1024, dtype=torch.int32, device=dev),
                                     box=torch.zeros(1024, 4, dtype=torch.int32, device=dev), t=torch.zeros(1024, 4, dtype=torch.float64, device=dev),
-                                    iou=torch.zeros(1024, dtype=torch.float64, device=dev))
+                                    iou=torch.zeros(1024, dtype=torch.float64, device=dev), h_cls=torch.zeros(1024, dtype=torch.int32).pin_memory(),
+                                    h_n=torch.zeros(1, dtype=torch.int32).pin_memory(), sel=torch.zeros(1024, dtype=torch.int32, device=dev),
+                                    h_sel=torch.zeros(1024, dtype=torch.int32).pin_memory())
         P = self._plans[key]
-        g = len(gt_boxes)
-        gt = torch.from_numpy(np.ascontiguousarray(gt_boxes, dtype=np.float64).reshape(-1, 4)).to(dev)
-        gc = torch.from_numpy(np.ascontiguousarray(gt_cls, dtype=np.int32)).to(dev)
-        rc = self.lib.radnet_roi_targets(self.ctx.h, R_dev.data_ptr(), int(n), gt.data_ptr(), gc.data_ptr(), g, int(width), int(height), int(rw), int(rh),
+        rc = self.lib.radnet_roi_targets(self.ctx.h, R_dev.data_ptr(), int(n_max), gt["boxes"].data_ptr() if gt["g"] else None,
+                                         gt["cls"].data_ptr() if gt["g"] else None, gt["g"], int(width), int(height), int(rw), int(rh),
                                          float(self.C.rpn_stride), float(self.C.classifier_min_overlap), float(self.C.classifier_max_overlap),
                                          self.regr_std.ctypes.data_as(C.POINTER(C.c_double)), int(self.bg), P["keep"].data_ptr(), P["cls"].data_ptr(),
-                                         P["box"].data_ptr(), P["t"].data_ptr(), P["iou"].data_ptr())
+                                         P["box"].data_ptr(), P["t"].data_ptr(), P["iou"].data_ptr(), n_dev.data_ptr())
         self.ctx.check(rc, "radnet_roi_targets")
-        return P
+        P["h_cls"][:n_max].copy_(P["cls"][:n_max], non_blocking=True)
+        P["h_n"].copy_(n_dev, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        n = int(P["h_n"][0])
+        return P, P["h_cls"].numpy()[:max(n, 0)], n
 
     def pack_roi_batch(self, P, sel, hp):
-        sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32)).to(self.dev)
-        self.ctx.call("radnet_roi_batch_pack", sel_t, len(sel), P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"], hp["y1"], hp["y2"])
+        k = len(sel)
+        P["h_sel"][:k] = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32))
+        P["sel"][:k].copy_(P["h_sel"][:k], non_blocking=True)
+        self.ctx.call("radnet_roi_batch_pack", P["sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"], hp["y1"], hp["y2"])
+
+
+def _uniform_table_probs(chan_of_item, neg_chans, n_total):
+    """The reference builds p[i] = (count[ch_i] / n) / count[ch_i] from the NEGATIVES' channel histogram
+    (utils.py:789-795, 804-810) and raises KeyError for a channel without negatives.  Vectorised: the same IEEE
+    operations element-wise, hence the same p and the same draws."""
+    chans, counts = np.unique(neg_chans, return_counts=True)
+    idx = np.searchsorted(chans, chan_of_item)
+    idx_c = np.minimum(idx, len(chans) - 1) if len(chans) else idx
+    bad = (idx >= len(chans)) | (chans[idx_c] != chan_of_item) if len(chans) else np.ones(len(chan_of_item), bool)
+    if bad.any():
+        raise KeyError(int(chan_of_item[np.argmax(bad)]))
+    cnt = counts[idx_c]
+    return (cnt / n_total) / cnt
 
 
 def subsample_valid(valid, overlap, max_regions=256):
@@ -613,16 +659,12 @@ def subsample_valid(valid, overlap, max_regions=256):
     n_pos, n_neg = len(pos[0]), len(neg[0])
     half = int(max_regions / 2)
     if n_pos > max_regions / 2:
-        chans, counts = np.unique(neg[0], return_counts=True)
-        table = dict(zip(chans.tolist(), counts.tolist()))
-        p = [(table[int(ch)] / n_pos) / table[int(ch)] for ch in pos[0]]    # KeyError as in the reference (utils.py:789-795)
+        p = _uniform_table_probs(pos[0], neg[0], n_pos)
         off = np.random.choice(n_pos, n_pos - half, replace=False, p=p)
         valid[pos[0][off], pos[1][off], pos[2][off]] = 0
         n_pos = half
     if n_neg + n_pos > max_regions:
-        chans, counts = np.unique(neg[0], return_counts=True)
-        table = dict(zip(chans.tolist(), counts.tolist()))
-        p = [(table[int(ch)] / n_neg) / table[int(ch)] for ch in neg[0]]
+        p = _uniform_table_probs(neg[0], neg[0], n_neg)
         off = np.random.choice(n_neg, n_neg - n_pos, replace=False, p=p)
         valid[neg[0][off], neg[1][off], neg[2][off]] = 0
     return n_pos

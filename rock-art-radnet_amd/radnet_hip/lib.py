@@ -66,6 +66,8 @@ def load_library():
         "radnet_sync": (C.c_int, [vp]),
         "radnet_version": (C.c_int, []),
         "radnet_set_workspace": (C.c_int, [vp, vp, u64]),
+        "radnet_set_autotune": (C.c_int, [vp, C.c_int]),
+        "radnet_tuned_shapes": (C.c_int, [vp]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
         "radnet_timing_reset": (C.c_int, [vp]),
@@ -91,7 +93,7 @@ def load_library():
                                             f64, f64, vp, vp, vp, vp, vp, vp]),
         "radnet_anchor_targets_pack": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f64, vp, vp]),
         "radnet_roi_targets": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f64, f64, f64, C.POINTER(f64), i32,
-                                         vp, vp, vp, vp, vp]),
+                                         vp, vp, vp, vp, vp, vp]),
         "radnet_roi_batch_pack": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]),
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),

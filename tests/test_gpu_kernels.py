@@ -430,7 +430,7 @@ def test_roi_targets_golden(ctx):
         iou = torch.zeros(n, dtype=torch.float64, device="cuda")
         Rd, gtd, gcd = dev(R), dev(gt), dev(gc)        # keep the device buffers alive across the call
         rc = ctx.lib.radnet_roi_targets(ctx.h, Rd.data_ptr(), n, gtd.data_ptr(), gcd.data_ptr(), len(gt), W, H, rw, rh, 16.0, 0.1, 0.5,
-                                        std.ctypes.data_as(C.POINTER(C.c_double)), 6, keep.data_ptr(), cls.data_ptr(), box.data_ptr(), t.data_ptr(), iou.data_ptr())
+                                        std.ctypes.data_as(C.POINTER(C.c_double)), 6, keep.data_ptr(), cls.data_ptr(), box.data_ptr(), t.data_ptr(), iou.data_ptr(), None)
         ctx.check(rc, "roi_targets")
         k = keep.cpu().numpy().astype(bool)
         X, Y1, Y2 = g[f"c{i}_X"], g[f"c{i}_Y1"], g[f"c{i}_Y2"]
