@@ -185,6 +185,16 @@ int radnet_roi_targets(radnet_ctx* ctx, const int64_t* rois, int32_t n, const do
 int radnet_roi_batch_pack(radnet_ctx* ctx, const int32_t* sel, int32_t r, const int32_t* cls, const int32_t* box,
                           const double* t, int32_t nc, int32_t bg_class, float* rois_out, float* y1, float* y2);
 
+/* ---- host-only helper (HOST pointers, no GPU work) ------------------------------------------------
+ * One round of NumPy's legacy RandomState.choice(n, size, replace=False, p=p) as used by utils.py:797,812.
+ * live_p / live_idx [*n_live_io]: the still non-zero probabilities and their indices (increasing); the round does
+ * cumsum + normalise over them (bit-identical to NumPy's cumsum over the full p: zeroed entries add 0.0), maps the
+ * k uniforms `x` (drawn by the caller with np.random.random_sample, so the global MT19937 stream is consumed
+ * exactly as NumPy would) through searchsorted(side='right'), appends first occurrences to found[n_found...] and
+ * removes them from the live lists.  Returns the number appended.  cdf: scratch [n] doubles; sel: scratch [n] bytes. */
+int64_t radnet_host_choice_round(double* live_p, int64_t* live_idx, int64_t* n_live_io, int64_t* found, int64_t n_found,
+                                 const double* x, int64_t k, double* cdf, uint8_t* sel);
+
 /* ---- small utilities ---------------------------------------------------------------------------- */
 /* uint8 BGR HWC image -> fp32 NHWC with `cpad` channels (zeros beyond 3), minus the caffe BGR means
  * (RADNet.py:83-87 / utils.py:468-472 with keras 'caffe' preprocess_input). */

@@ -649,6 +649,33 @@ def _uniform_table_probs(chan_of_item, neg_chans, n_total):
     return (cnt / n_total) / cnt
 
 
+def choice_without_replacement(n, size, p):
+    """== np.random.choice(n, size, replace=False, p=p) on NumPy's GLOBAL legacy RandomState: same result, same
+    consumption of the MT19937 stream (the uniforms are drawn here with np.random.random_sample, round by round,
+    exactly as RandomState.choice does), with each round's cumsum / searchsorted / de-duplication done by the C
+    helper radnet_host_choice_round instead of ~10 NumPy passes (4 ms -> 0.3 ms for 20 000 anchors)."""
+    lib = L.load_library()
+    p = np.array(p, dtype=np.float64, copy=True)
+    if p.ndim != 1 or p.shape[0] != n:
+        raise ValueError("'a' and 'p' must have same size")
+    if size > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    if np.count_nonzero(p > 0) < size:
+        raise ValueError("Fewer non-zero entries in p than size")
+    found = np.zeros(max(size, 1), dtype=np.int64)
+    live_idx = np.flatnonzero(p > 0).astype(np.int64)        # zero entries only ever add 0.0 to NumPy's cumsum
+    live_p = np.ascontiguousarray(p[live_idx])
+    n_live = np.array([live_idx.shape[0]], dtype=np.int64)
+    cdf = np.empty(n, dtype=np.float64)
+    sel = np.empty(n, dtype=np.uint8)
+    n_uniq = 0
+    while n_uniq < size:
+        x = np.random.random_sample(size - n_uniq)
+        n_uniq += int(lib.radnet_host_choice_round(live_p.ctypes.data, live_idx.ctypes.data, n_live.ctypes.data, found.ctypes.data, n_uniq,
+                                                   x.ctypes.data, x.shape[0], cdf.ctypes.data, sel.ctypes.data))
+    return found[:size]
+
+
 def subsample_valid(valid, overlap, max_regions=256):
     """Host half of utils.calc_region_props (utils.py:777-813): random disabling of surplus positives /
     negatives on the *global NumPy RNG stream*, which is part of the reference's contract (train.py:41,134).
@@ -660,12 +687,12 @@ def subsample_valid(valid, overlap, max_regions=256):
     half = int(max_regions / 2)
     if n_pos > max_regions / 2:
         p = _uniform_table_probs(pos[0], neg[0], n_pos)
-        off = np.random.choice(n_pos, n_pos - half, replace=False, p=p)
+        off = choice_without_replacement(n_pos, n_pos - half, p)
         valid[pos[0][off], pos[1][off], pos[2][off]] = 0
         n_pos = half
     if n_neg + n_pos > max_regions:
         p = _uniform_table_probs(neg[0], neg[0], n_neg)
-        off = np.random.choice(n_neg, n_neg - n_pos, replace=False, p=p)
+        off = choice_without_replacement(n_neg, n_neg - n_pos, p)
         valid[neg[0][off], neg[1][off], neg[2][off]] = 0
     return n_pos
 

@@ -95,6 +95,7 @@ def load_library():
         "radnet_roi_targets": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f64, f64, f64, C.POINTER(f64), i32,
                                          vp, vp, vp, vp, vp, vp]),
         "radnet_roi_batch_pack": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]),
+        "radnet_host_choice_round": (i64, [vp, vp, vp, vp, i64, vp, i64, vp, vp]),
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
