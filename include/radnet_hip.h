@@ -199,6 +199,11 @@ int64_t radnet_host_choice_round(double* live_p, int64_t* live_idx, int64_t* n_l
 /* uint8 BGR HWC image -> fp32 NHWC with `cpad` channels (zeros beyond 3), minus the caffe BGR means
  * (RADNet.py:83-87 / utils.py:468-472 with keras 'caffe' preprocess_input). */
 int radnet_preprocess_bgr(radnet_ctx* ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cpad, float* out);
+/* cv2.resize(img, (dw, dh), interpolation=INTER_CUBIC) for uint8 HWC images (RADNet.py:72, utils.py:442-446):
+ * a = -0.75 bicubic, half-pixel centres, replicated borders, OpenCV's 11-bit fixed-point arithmetic.
+ * Parity unpinned (OpenCV absent offline). */
+int radnet_resize_bicubic_u8(radnet_ctx* ctx, const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh,
+                             int32_t dw, int32_t channels);
 int radnet_fill_zero(radnet_ctx* ctx, void* p, uint64_t bytes);
 /* y = x * alpha (n floats); used to average gradients after all-reduce */
 int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha);

@@ -1,0 +1,226 @@
+"""Detector facade with the reference's construct / predict surface (faster_rcnn/RADNet.py).
+
+    RADNet(C, model_rpn, model_detector, preprocess_func)              RADNet.py:33-41
+    .predict(images) -> [{'class','prob','x1','y1','x2','y2'}, ...]     RADNet.py:502-718
+    .predict_from_path(path)                                           RADNet.py:482-500
+    .format_img / .apply_spatial_pyramid_pooling / .final_nms / .get_real_coordinates
+    load_radnet(config_path)                                           RADNet.py:721-775
+
+The model objects are duck-typed exactly as in the reference (anything with .predict works, which is how the
+golden tests drive this class with closed-form fake models); load_radnet() builds them on the HIP engine.
+NMS runs in libradnet_hip.so through faster_rcnn.rpn; the tile resize runs on the device (radnet_resize_bicubic_u8).
+"""
+import pickle
+import sys
+
+import numpy as np
+
+from . import rpn
+from .utils import get_new_img_size  # noqa: F401  (re-exported like the reference's star import)
+
+
+def _spans(length, tile, step):
+    """Sliding-window spans along one axis (RADNet.py:519-535): starts every `step`, windows that fit, plus one
+    window flush with the far edge; duplicates removed, sorted."""
+    starts = np.arange(0, length, step)
+    ends = starts + tile
+    ok = ends <= length
+    pairs = {(int(s), int(e)) for s, e in zip(starts[ok], ends[ok])}
+    pairs.add((max(0, length - tile), int(length)))
+    return sorted(pairs)
+
+
+class RADNet():
+
+    def __init__(self, C, model_rpn, model_detector, preprocess_func):
+        self.is_object_threshold = 0.5
+        self.bbox_threshold = 0.7
+        self.C = C
+        self.model_rpn = model_rpn
+        self.model_detector = model_detector
+        self.preprocess_func = preprocess_func
+        self.class_mapping = {v: k for k, v in C.class_mapping.items()}
+
+    # ---- geometry helpers ------------------------------------------------------------------------------------
+    def get_real_coordinates(self, ratio, x1, y1, x2, y2):
+        """Back to source-image pixels: floor-division by the resize ratio, then round (RADNet.py:44-51)."""
+        return tuple(int(round(v // ratio)) for v in (x1, y1, x2, y2))
+
+    def format_img_size(self, img):
+        """Short side -> C.img_size, long side truncated (RADNet.py:53-74); bicubic resize on the device."""
+        side = float(self.C.img_size)
+        height, width = img.shape[:2]
+        if width <= height:
+            ratio = side / width
+            new_w, new_h = int(side), int(ratio * height)
+        else:
+            ratio = side / height
+            new_w, new_h = int(ratio * width), int(side)
+        if (new_h, new_w) != (height, width):
+            img = resize_cubic(img, new_w, new_h)
+        return img, ratio
+
+    def format_img_channels(self, img):
+        img = img[:, :, (2, 1, 0)].astype(np.float32)          # BGR -> RGB (RADNet.py:83-84)
+        return self.preprocess_func(np.expand_dims(img, axis=0))
+
+    def format_img(self, img):
+        img, ratio = self.format_img_size(img)
+        return self.format_img_channels(img), ratio
+
+    # ---- classifier head over the proposals -----------------------------------------------------------------------
+    def apply_spatial_pyramid_pooling(self, R, feature_map):
+        """RADNet.py:104-154.  R (n,4) xywh in feature-map units.  The RoIs go through the detector n_rois at a
+        time, the last chunk padded with copies of its first RoI; confident non-background RoIs are decoded with
+        their class's deltas and scaled to resized-image pixels."""
+        C = self.C
+        k = C.n_rois
+        stride = C.rpn_stride
+        std = C.classifier_regr_std
+        bboxes, probs = {}, {}
+        for start in range(0, R.shape[0], k):
+            chunk = R[start:start + k, :]
+            if chunk.shape[0] < k:
+                padded = np.zeros((k, chunk.shape[1])).astype(chunk.dtype)
+                padded[:chunk.shape[0]] = chunk
+                padded[chunk.shape[0]:] = chunk[0]
+                chunk = padded
+            ROIs = np.expand_dims(chunk, axis=0)
+            P_cls, P_regr = self.model_detector.predict([feature_map, ROIs])
+            for ii in range(P_cls.shape[1]):
+                scores = P_cls[0, ii, :]
+                best = int(np.argmax(scores))
+                if np.max(scores) < self.bbox_threshold or best == P_cls.shape[2] - 1:
+                    continue
+                name = self.class_mapping[best]
+                x, y, w, h = ROIs[0, ii, :]
+                try:
+                    tx, ty, tw, th = P_regr[0, ii, 4 * best:4 * (best + 1)]
+                    x, y, w, h = rpn.apply_regr(x, y, w, h, tx / std[0], ty / std[1], tw / std[2], th / std[3])
+                except Exception:
+                    pass
+                bboxes.setdefault(name, []).append([stride * x, stride * y, stride * (x + w), stride * (y + h)])
+                probs.setdefault(name, []).append(np.max(scores))
+        return bboxes, probs
+
+    def final_nms(self, boxes, probs, obj_avg_threshold=0.2, obj_confidence_threshold=0.8, n_obj_avg=5):
+        """RADNet.py:156-240: greedy clustering around the current best box (IoU > obj_avg_threshold); each cluster
+        becomes the mean of its members above obj_confidence_threshold, or of its n_obj_avg best members."""
+        if len(boxes) == 0:
+            return []
+        x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+        np.testing.assert_array_less(x1, x2)
+        np.testing.assert_array_less(y1, y2)
+        if boxes.dtype.kind == "i":
+            boxes = boxes.astype("float")
+        area = (x2 - x1) * (y2 - y1)
+        order = np.argsort(probs, kind="stable")
+        clusters = []
+        while len(order) > 0:
+            last = len(order) - 1
+            top, rest = order[last], order[:last]
+            iw = np.maximum(0, np.minimum(x2[top], x2[rest]) - np.maximum(x1[top], x1[rest]))
+            ih = np.maximum(0, np.minimum(y2[top], y2[rest]) - np.maximum(y1[top], y1[rest]))
+            inter = iw * ih
+            overlap = inter / (area[top] + area[rest] - inter + 1e-6)
+            members = np.concatenate((np.where(overlap > obj_avg_threshold)[0], [last]))
+            mp = probs[order[members]]
+            if mp.max() < obj_confidence_threshold:
+                chosen = order[members][-n_obj_avg:]
+            else:
+                chosen = order[members][np.nonzero(mp > obj_confidence_threshold)[0]]
+            clusters.append(chosen)
+            order = np.delete(order, members)
+        new_boxes = [np.rint(boxes[c].mean(axis=0)).astype('int') for c in clusters]
+        new_probs = [probs[c].mean() for c in clusters]
+        return np.array(new_boxes), np.array(new_probs)
+
+    # ---- inference ---------------------------------------------------------------------------------------------------
+    def _detect(self, img):
+        """One network pass on an image or tile: {class: (boxes in source px, probs)} after the per-class NMS 0.2."""
+        X, ratio = self.format_img(img)
+        Y1, Y2, F = self.model_rpn.predict(X)
+        R = rpn.rpn_to_roi(Y1, Y2, self.C, overlap_thresh=0.7)
+        R[:, 2] -= R[:, 0]
+        R[:, 3] -= R[:, 1]
+        bboxes, probs = self.apply_spatial_pyramid_pooling(R, F)
+        out = {}
+        for key in bboxes:
+            nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
+            real = [self.get_real_coordinates(ratio, *nb[j, :]) for j in range(nb.shape[0])]
+            out[key] = (real, [npr[j] for j in range(nb.shape[0])])
+        return out
+
+    def predict(self, images):
+        """RADNet.py:502-718: tile -> RPN -> NMS -> RoI crop-resize -> classifier -> per-class NMS, box-averaging
+        merge per image, then NMS 0.4 across images."""
+        C = self.C
+        all_boxes, all_probs = {}, {}
+        for img in images:
+            boxes_img, probs_img = {}, {}
+
+            def collect(det, ox, oy):
+                for key, (real, pr) in det.items():
+                    for (rx1, ry1, rx2, ry2), p in zip(real, pr):
+                        boxes_img.setdefault(key, []).append([ox + rx1, oy + ry1, ox + rx2, oy + ry2])
+                        probs_img.setdefault(key, []).append(p)
+
+            if C.max_n_tiles_train > 0:                 # the reference gates tiling on this training knob (RADNet.py:511)
+                h, w = img.shape[:2]
+                for (ty0, ty1) in _spans(h, C.tile_size, C.tile_overlap):
+                    for (tx0, tx1) in _spans(w, C.tile_size, C.tile_overlap):
+                        collect(self._detect(np.copy(img[ty0:ty1, tx0:tx1, :])), tx0, ty0)
+            if C.include_full_img:
+                collect(self._detect(img), 0, 0)
+            for key in boxes_img:
+                nb, npr = self.final_nms(np.array(boxes_img[key]), np.array(probs_img[key]), obj_avg_threshold=0.2,
+                                         obj_confidence_threshold=0.8, n_obj_avg=5)
+                for j in range(nb.shape[0]):
+                    all_boxes.setdefault(key, []).append(list(nb[j, :]))
+                    all_probs.setdefault(key, []).append(npr[j])
+        dets = []
+        for key in all_boxes:
+            nb, npr = rpn.non_max_suppression_fast(np.array(all_boxes[key]), np.array(all_probs[key]), overlap_thresh=0.4)
+            for j in range(nb.shape[0]):
+                x1, y1, x2, y2 = nb[j, :]
+                dets.append({'class': key, 'prob': npr[j], 'x1': x1, 'y1': y1, 'x2': x2, 'y2': y2})
+        return dets
+
+    def predict_from_path(self, img_path):
+        """RADNet.py:482-500 (needs an image decoder; OpenCV is the reference's and is absent here)."""
+        try:
+            import cv2  # noqa: F401
+        except ImportError as e:
+            raise NotImplementedError("predict_from_path needs OpenCV to decode images; pass decoded BGR arrays to predict()") from e
+        from .utils_io import get_image
+        C = self.C
+        types = C.img_types if C.use_img_type else [C.img_types[0]]
+        return self.predict([get_image(img_path, [t], random_type=False) for t in types])
+
+
+def resize_cubic(img, new_w, new_h):
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_CUBIC) on the device (uint8 HWC)."""
+    import torch
+    from radnet_hip import runtime as rt
+    ctx = rt.default_context()
+    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
+    dst = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
+    ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], dst, new_h, new_w, img.shape[2])
+    return dst.cpu().numpy()
+
+
+def load_radnet(config_path, device_index=0):
+    """RADNet.py:721-775: unpickle the Config, build the RPN (3 outputs) and detector models, load C.weights_path."""
+    from . import models
+    with open(config_path, 'rb') as f:
+        C = pickle.load(f)
+    if C.network == 'resnet50':
+        from .base_models import resnet50 as base_model
+    elif C.network == 'vgg16':
+        from .base_models import vgg16 as base_model
+    else:
+        print('Not a valid base model!')
+        sys.exit(1)
+    _, _, model_all, model_rpn, model_detector = models.build_models(C, device_index=device_index)
+    model_all.load_weights(str(C.weights_path).replace('\\', '/'), by_name=True)
+    return RADNet(C, model_rpn, model_detector, base_model.preprocess)

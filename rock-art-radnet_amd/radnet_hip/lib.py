@@ -97,6 +97,7 @@ def load_library():
         "radnet_roi_batch_pack": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]),
         "radnet_host_choice_round": (i64, [vp, vp, vp, vp, i64, vp, i64, vp, vp]),
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "radnet_resize_bicubic_u8": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
     }

@@ -1,0 +1,223 @@
+"""Drop-in package (faster_rcnn.*) on the GPU: function-style API vs goldens from the reference, RADNet.predict with
+fake models vs the reference's own output, Keras-like models vs the oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_rpn_functions_match_reference_goldens():
+    from faster_rcnn import rpn
+    from faster_rcnn.config import Config
+    g = load_golden("rpn_to_roi")
+    for i in (0, 3, 4, 6):
+        C = Config(); C.anchor_box_scales = [int(v) for v in g[f"c{i}_scales"]]
+        R = rpn.rpn_to_roi(g[f"c{i}_cls"], g[f"c{i}_regr"], C, use_regr=True, max_boxes=int(g[f"c{i}_max"]), overlap_thresh=float(g[f"c{i}_thr"]))
+        assert R.dtype == np.int64 and np.array_equal(R, g[f"c{i}_R"])
+    g = load_golden("nms")
+    for i in range(int(g["n_cases"])):
+        b, p = rpn.non_max_suppression_fast(g[f"c{i}_boxes"], g[f"c{i}_probs"], overlap_thresh=float(g[f"c{i}_thr"]), max_boxes=int(g[f"c{i}_max"]))
+        assert np.array_equal(b, g[f"c{i}_out_boxes"]) and np.array_equal(p, g[f"c{i}_out_probs"])
+    assert rpn.non_max_suppression_fast(np.zeros((0, 4)), np.zeros(0)) == []
+    with pytest.raises(AssertionError):
+        rpn.non_max_suppression_fast(np.array([[1., 1., 1., 4.]]), np.array([0.3]))
+    g = load_golden("calc_iou")
+    C = Config()
+    classes = {v: k for k, v in C.class_mapping.items()}
+    for i in range(int(g["n_cases"])):
+        W, H = (int(v) for v in g[f"c{i}_wh"])
+        bboxes = [{"class": classes[int(c)], "x1": b[0], "y1": b[1], "x2": b[2], "y2": b[3]} for b, c in zip(g[f"c{i}_gt_boxes"], g[f"c{i}_gt_cls"])]
+        X, Y1, Y2, ious = rpn.calc_iou(g[f"c{i}_R"], {"bboxes": bboxes, "width": W, "height": H}, C, C.class_mapping)
+        assert np.array_equal(X, g[f"c{i}_X"]) and np.array_equal(Y1, g[f"c{i}_Y1"])
+        assert np.array_equal(np.array(ious), g[f"c{i}_ious"])
+        assert np.array_equal(Y2[..., :24], g[f"c{i}_Y2"][..., :24])
+        assert np.allclose(Y2[..., 24:], g[f"c{i}_Y2"][..., 24:], rtol=5e-16, atol=0)        # device log vs NumPy log: 1 ulp
+    bb = [{"class": "boat", "x1": 1900, "x2": 1990, "y1": 1100, "y2": 1190}]
+    assert rpn.calc_iou(np.array([[0, 0, 2, 2]]), {"bboxes": bb, "width": 2000, "height": 1200}, C, C.class_mapping) == (None, None, None, None)
+
+
+def test_calc_region_props_matches_reference_goldens():
+    from faster_rcnn import utils
+    from faster_rcnn.base_models import resnet50
+    from faster_rcnn.config import Config
+    g = load_golden("calc_region_props")
+    for i in range(int(g["n_cases"])):
+        W, H, rw, rh, isz, rseed = (int(v) for v in g[f"c{i}_wh"])
+        C = Config(); C.img_size = isz
+        bboxes = [{"class": "bg" if bg else "boat", "x1": b[0], "y1": b[1], "x2": b[2], "y2": b[3]} for b, bg in zip(g[f"c{i}_gt_boxes"], g[f"c{i}_gt_is_bg"])]
+        np.random.seed(rseed)
+        ycls, yregr, best, n_pos = utils.calc_region_props(C, {"bboxes": bboxes}, W, H, rw, rh, resnet50.get_img_output_length)
+        assert n_pos == int(g[f"c{i}_n_pos"])
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[f"c{i}_rng_after"])
+        assert np.array_equal(ycls, g[f"c{i}_y_rpn_cls"])
+        assert np.array_equal(best, g[f"c{i}_best_anchor"])
+        ref = g[f"c{i}_y_rpn_regr"]
+        assert np.array_equal(yregr[:, :48], ref[:, :48])
+        assert np.array_equal(yregr.astype(np.float32), ref.astype(np.float32))          # what the network consumes
+        assert np.all(np.abs(yregr - ref) <= 4.5e-16 * np.abs(ref))
+
+
+class _FakeDet:
+    def __init__(self, nc, seed):
+        from test_oracle_glue import fake_detector
+        self._f = fake_detector(nc, seed, [])
+
+    def predict(self, inputs):
+        return self._f(inputs[1])
+
+
+class _FakeRPN:
+    """The golden generator's closed-form RPN stand-in."""
+    def __init__(self, A, seed):
+        self.A, self.seed = A, seed
+
+    def predict(self, X):
+        from oracle import glue
+        h, w = glue.resnet50_feat_len(X.shape[1]), glue.resnet50_feat_len(X.shape[2])
+        rs = np.random.RandomState(self.seed + int(abs(float(X.sum()))) % 1000)
+        n = h * w * self.A
+        cls = (rs.permutation(n).astype(np.float32) / np.float32(n)).reshape(1, h, w, self.A)
+        regr = (rs.standard_normal((1, h, w, 4 * self.A)) * 2.0).astype(np.float32)
+        return [cls, regr, rs.standard_normal((1, h, w, 8)).astype(np.float32)]
+
+
+def test_radnet_predict_matches_reference_output():
+    """RADNet.predict (tiling, RPN->NMS->classifier decode->per-class NMS->box-averaging merge->cross-image NMS) with
+    the same fake models the reference's RADNet was driven with: identical detections."""
+    from faster_rcnn.config import Config
+    from faster_rcnn.RADNet import RADNet
+    g = load_golden("predict_fake")
+    C = Config(); C.tile_size = 600; C.tile_overlap = 300; C.img_size = 600
+    net = RADNet(C, _FakeRPN(12, 8), _FakeDet(7, 2), lambda x: x - np.float32(100.0))
+    dets = net.predict([g["img"]])
+    assert len(dets) == int(g["n"])
+    assert [d["class"] for d in dets] == list(g["classes"])
+    # The fake detector saturates (many probabilities are exactly equal), and among EQUAL scores the reference's
+    # order is whatever np.argsort's unstable default produced (SURVEY.md A.4 rule 6); this build's rule is "stable
+    # ascending, walk from the end".  Compare per class as multisets: same boxes, same probabilities.
+    got = sorted((d["class"], int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"]), float(d["prob"])) for d in dets)
+    ref = sorted((str(c), int(b[0]), int(b[1]), int(b[2]), int(b[3]), float(p)) for c, b, p in zip(g["classes"], g["boxes"], g["probs"]))
+    assert got == ref
+
+
+@pytest.fixture(scope="module")
+def models():
+    from faster_rcnn import models as M
+    from faster_rcnn.config import Config
+    from oracle import dense
+    C = Config(); C.img_size = 300
+    P = dense.init_params(seed=3)
+    return C, P, M.build_models(C, weights=copy.deepcopy(P))
+
+
+def test_keras_like_models_vs_oracle(models):
+    from oracle import dense, glue
+    from faster_rcnn.base_models import resnet50
+    C, P, (m_rpn, m_cls, m_all, m_rpn3, m_det) = models
+    P = copy.deepcopy(P)
+    rs = np.random.RandomState(21)
+    img = rs.randint(0, 256, (300, 480, 3)).astype(np.uint8)
+    X = resnet50.preprocess(img[:, :, (2, 1, 0)].astype(np.float32)[None])
+    assert np.allclose(X, dense.preprocess_caffe_bgr(img), atol=1e-4)
+    # inference flavour: 3 outputs
+    Y1, Y2, F = m_rpn3.predict(X)
+    p, r, cache = dense.rpn_forward(P, dense.base_forward(P, X))
+    assert Y1.shape == p.shape and Y2.shape == r.shape and F.shape == cache["F"].shape
+    assert np.abs(Y1 - p).max() < 1e-3 and np.abs(Y2 - r).max() < 1e-3 * np.abs(r).max()
+    # detector on the returned feature map
+    rois = np.stack([rs.randint(0, 20, 20), rs.randint(0, 10, 20), rs.randint(1, 9, 20), rs.randint(1, 8, 20)], 1)[None]
+    pc, pr = m_det.predict([F, rois])
+    rc, rr, _ = dense.head_forward(P, cache["F"], rois[0].astype(np.float32), 7)
+    assert np.abs(pc - rc).max() < 1e-3 and np.abs(pr - rr).max() < 1e-3 * max(1.0, np.abs(rr).max())
+    # a foreign feature-map array (not the cached one) takes the upload path and gives the same answer
+    pc2, _ = m_det.predict([F.copy(), rois])
+    assert np.array_equal(pc, pc2)
+    # RPN train / test on batch: Keras order [total, cls, regr]
+    fh, fw = F.shape[1:3]
+    valid = (rs.uniform(size=(1, fh, fw, 12)) < 0.05).astype(np.float32)
+    ov = ((rs.uniform(size=(1, fh, fw, 12)) < 0.3) * valid).astype(np.float32)
+    Y = [np.concatenate([valid, ov], -1), np.concatenate([np.repeat(ov, 4, -1), rs.standard_normal((1, fh, fw, 48)).astype(np.float32)], -1)]
+    lt = m_rpn.test_on_batch(X, Y)
+    ref, grads = dense.rpn_losses_and_grads(P, cache["F"], Y[0], Y[1], 12, True)
+    assert abs(lt[1] - ref[1]) < 1e-3 * abs(ref[1]) and abs(lt[2] - ref[2]) < 1e-3 * abs(ref[2]) + 1e-6
+    l1 = m_rpn.train_on_batch(X, Y)
+    assert abs(l1[0] - (l1[1] + l1[2])) < 1e-5 and abs(l1[1] - lt[1]) < 1e-6
+    l2 = m_rpn.test_on_batch(X, Y)
+    assert l2[0] < l1[0]                                     # one Adam step on the same batch lowers the loss
+    # classifier train on batch: [total, cls, regr, acc]
+    cls = rs.randint(0, 7, 20)
+    T1 = np.eye(7, dtype=np.float32)[cls][None]
+    lab = np.zeros((20, 24), np.float32)
+    for i, c in enumerate(cls):
+        if c != 6:
+            lab[i, 4 * c:4 * c + 4] = 1
+    T2 = np.concatenate([lab, rs.standard_normal((20, 24)).astype(np.float32) * lab], -1)[None]
+    d0 = m_cls.test_on_batch([X, rois], [T1, T2])
+    refd, _ = dense.head_losses_and_grads(P, cache["F"], rois[0].astype(np.float32), T1, T2, 7)
+    assert abs(d0[1] - refd[1]) < 2e-3 * abs(refd[1]) and abs(d0[2] - refd[2]) < 2e-3 * abs(refd[2]) + 1e-6 and abs(d0[3] - refd[3]) < 1e-6
+    d1 = m_cls.train_on_batch([X, rois], [T1, T2])
+    d2 = m_cls.test_on_batch([X, rois], [T1, T2])
+    assert len(d1) == 4 and d2[0] < d1[0]
+
+
+def test_save_load_weights_roundtrip(models, tmp_path):
+    C, P, (m_rpn, m_cls, m_all, m_rpn3, m_det) = models
+    path = str(tmp_path / "weights.npz")
+    m_all.save_weights(path)
+    z = np.load(path)
+    assert "rpn_conv1/kernel" in z.files and "bn_conv1/gamma" in z.files and z["res5a_branch2a/kernel"].shape == (1, 1, 1024, 512)
+    X = np.random.RandomState(3).standard_normal((1, 300, 300, 3)).astype(np.float32) * 50
+    a = m_rpn3.predict(X)
+    m_all.load_weights(path, by_name=True)
+    b = m_rpn3.predict(X)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    with pytest.raises(NotImplementedError):
+        m_all.load_weights(str(tmp_path / "weights.hdf5"))
+
+
+def test_cfg3_predict_tile_2048(models):
+    """BASELINE config 3: predict.py path on a 2048x2048 synthetic tile (seed 4), resized to short side C.img_size on
+    the device.  Stage-wise against the oracle on the device's own tensors: proposals bit-exact, per-chunk classifier
+    outputs within fp32 tolerance, and the decoded detections identical to the oracle's decode of those outputs."""
+    from faster_rcnn.RADNet import RADNet, resize_cubic
+    from faster_rcnn.base_models import resnet50
+    from oracle import dense, glue
+    C, P0, (m_rpn, m_cls, m_all, m_rpn3, m_det) = models
+    tile = np.random.RandomState(4).randint(0, 256, (2048, 2048, 3)).astype(np.uint8)
+    net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+    X, ratio = net.format_img(tile)
+    assert X.shape == (1, 300, 300, 3) and abs(ratio - 300 / 2048) < 1e-12
+    small = resize_cubic(tile, 300, 300)
+    assert small.dtype == np.uint8 and 100 < small.mean() < 155 and small.std() < tile.std()      # low-pass of white noise
+    Y1, Y2, F = m_rpn3.predict(X)
+    from faster_rcnn import rpn
+    R = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
+    assert np.array_equal(R, glue.rpn_to_roi(Y1, Y2, C, True, 300, 0.7))
+    R[:, 2] -= R[:, 0]; R[:, 3] -= R[:, 1]
+    bb, pp = net.apply_spatial_pyramid_pooling(R, F)
+    W = m_all._s.eng.get_weights()
+    Pnow = copy.deepcopy(P0); Pnow.update(W)
+    calls = []
+
+    def oracle_det(rois):
+        pc, pr, _ = dense.head_forward(Pnow, F, rois[0].astype(np.float32), 7)
+        calls.append((pc, pr))
+        return [pc, pr]
+    # the oracle's classifier on the same feature map agrees chunk by chunk
+    pc_gpu, pr_gpu = m_det.predict([F, R[:20][None]])
+    pc_ref, pr_ref = oracle_det(R[:20][None])
+    assert np.abs(pc_gpu - pc_ref).max() < 2e-3 and np.abs(pr_gpu - pr_ref).max() < 2e-3 * max(1.0, np.abs(pr_ref).max())
+    # decode parity: the oracle's spp_decode fed with the DEVICE outputs reproduces the facade's boxes exactly
+    bb_ref, pp_ref = glue.spp_decode(R, lambda rois: m_det.predict([F, rois]), C)
+    assert sorted(bb) == sorted(bb_ref)
+    for k in bb:
+        assert np.array_equal(np.array(bb[k]), np.array(bb_ref[k])) and np.array_equal(np.array(pp[k]), np.array(pp_ref[k]))
+    dets = net.predict([tile])
+    assert isinstance(dets, list)
+    for d in dets:
+        assert set(d) == {"class", "prob", "x1", "y1", "x2", "y2"}
