@@ -28,6 +28,16 @@ def new_img_size(width, height, min_side):
     return int(f * width), min_side
 
 
+def allreduce_grad_arena(flat, world, group=None):
+    """Data-parallel exchange of one optimizer's flat gradient arena: SUM over ranks (RCCL over xGMI on the GPUs,
+    gloo in the CPU tests).  Returns the factor Adam applies to the summed gradient so that the update uses the MEAN
+    over all `world * images_per_rank` images (the caller divides by images_per_rank as well)."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
 class TrainStep:
 
     def __init__(self, eng, dist_group=None, world_size=1):
@@ -42,9 +52,7 @@ class TrainStep:
         self._det_l = torch.zeros(64, 3, dtype=torch.float32, device=dev)
 
     def _allreduce(self, arena):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(arena.g, op=dist.ReduceOp.SUM, group=self.group)
+        allreduce_grad_arena(arena.g, self.world, self.group)
 
     def _gt(self, s):
         """Device copy of a sample's ground truth (cached on the sample: uploaded once)."""
