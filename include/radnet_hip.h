@@ -210,6 +210,8 @@ int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha);
 /* out[i] = a[i]*b[i] + c[i]: refreshes the folded epilogue shift (BN scale * conv bias + BN shift,
  * FixedBatchNormalization.py:59-85) of the trainable head convs after an optimizer step. */
 int radnet_affine_vec(radnet_ctx* ctx, float* out, const float* a, const float* b, const float* c, int64_t n);
+/* g[i] = act[i] > 0 ? g[i] : 0 -- ReLU backward where it cannot ride a GEMM epilogue (VGG16 head, vgg16.py:98-101) */
+int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -589,6 +589,23 @@ extern "C" int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha) {
   return RADNET_OK;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) relu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (!(act[i] > 0.f)) g[i] = 0.f;
+}
+}  // namespace
+
+extern "C" int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n) {
+  if (!ctx || !g || !act) return RADNET_ERR_ARG;
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((int)b), dim3(256), 0, ctx->stream, g, act, (long long)n);
+  RADNET_CHECK_LAUNCH(ctx, "relu_mask");
+  return RADNET_OK;
+}
+
 extern "C" int radnet_affine_vec(radnet_ctx* ctx, float* out, const float* a, const float* b, const float* c, int64_t n) {
   if (!ctx || !out || !a || !b || !c) return RADNET_ERR_ARG;
   hipLaunchKernelGGL(affine_vec_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, out, a, b, c, (long long)n);

@@ -26,10 +26,13 @@ class Adam:
 class _Shared:
     def __init__(self, C, device_index=0, weights=None, lr=5e-5, bce_mode=0):
         from radnet_hip import synth
-        from radnet_hip.engine import FasterRCNNEngine
+        from radnet_hip import make_engine
         self.C = C
-        self.eng = FasterRCNNEngine(C, device_index=device_index, bce_mode=bce_mode, lr=lr)
-        self.W = weights if weights is not None else synth.synthetic_weights(seed=3, n_anchors=self.eng.A, n_classes=self.eng.nc)
+        self.eng = make_engine(C, device_index=device_index, bce_mode=bce_mode, lr=lr)
+        if weights is None:
+            gen = synth.synthetic_weights_vgg16 if C.network == "vgg16" else synth.synthetic_weights
+            weights = gen(seed=3, n_anchors=self.eng.A, n_classes=self.eng.nc)
+        self.W = weights
         self.eng.set_weights(self.W)
         self._x_key = None
         self._bp = None
@@ -141,7 +144,7 @@ class RPNModel(_ModelBase):
 class ClassifierModel(_ModelBase):
     """Model([img_input, roi_input], classifier) (train.py:210): base + RoI crop-resize + stage 5 + dense heads."""
 
-    def _prepare(self, inputs, targets=None):
+    def _prepare(self, inputs, targets=None, training=False):
         import torch
         eng = self._s.eng
         X, rois = inputs
@@ -152,7 +155,7 @@ class ClassifierModel(_ModelBase):
         if targets is not None:
             hp["y1"].copy_(torch.from_numpy(np.ascontiguousarray(targets[0], dtype=np.float32).reshape(rois.shape[0], -1)))
             hp["y2"].copy_(torch.from_numpy(np.ascontiguousarray(targets[1], dtype=np.float32).reshape(rois.shape[0], -1)))
-        eng.head_forward(hp)
+        eng.head_forward(hp, training=training)
         return hp
 
     def predict(self, inputs, **kw):
@@ -166,7 +169,7 @@ class ClassifierModel(_ModelBase):
     def train_on_batch(self, inputs, targets):
         eng = self._s.eng
         self._use_lr()
-        hp = self._prepare(inputs, targets)
+        hp = self._prepare(inputs, targets, training=True)
         eng.set_accumulate(hp["bwd"], False)
         eng.head_backward(hp, accumulate=False)
         eng.adam(eng.head_arena)

@@ -92,9 +92,13 @@ class FasterRCNNEngine:
     """ResNet50 Faster R-CNN on one MI355X.  `mode`: 'train' = train.py trainability (whole base frozen);
     inference uses the same object."""
 
+    NETWORK = "resnet50"
+    N_FEATURES = 1024
+    feat_len = staticmethod(feat_len)
+
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5, autotune=True):
-        if C_cfg.network != "resnet50":
-            raise L.RadnetError("engine: network %r not built yet (resnet50 only)" % (C_cfg.network,))
+        if C_cfg.network != self.NETWORK:
+            raise L.RadnetError("engine: %s asked to run network %r (use radnet_hip.make_engine)" % (type(self).__name__, C_cfg.network))
         self.C = C_cfg
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
@@ -529,7 +533,8 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
-    def head_forward(self, hp):
+    def head_forward(self, hp, training=False):
+        """classifier_layer forward (`training` only matters for the VGG16 head's Dropout)."""
         self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
         self._run(hp["fwd"])
         self.ctx.call("radnet_avgpool_fwd", hp["y5"], hp["R"], hp["hw"], 2048, hp["feat"])
@@ -558,7 +563,7 @@ class FasterRCNNEngine:
     def anchor_targets_launch(self, gt, width, height, rw, rh, slot=0):
         """Device half of utils.calc_region_props (utils.py:585-766) + ASYNC copy of the valid/overlap maps to pinned
         host memory.  The caller may enqueue unrelated GPU work (base forward) before anchor_targets_finish()."""
-        fw, fh = feat_len(rw), feat_len(rh)
+        fw, fh = self.feat_len(rw), self.feat_len(rh)
         A = self.A
         key = ("atgt", fh, fw, slot)
         if key not in self._plans:

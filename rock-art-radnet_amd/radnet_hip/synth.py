@@ -50,6 +50,29 @@ def synthetic_weights(seed=3, n_anchors=12, n_classes=7):
     return W
 
 
+def synthetic_weights_vgg16(seed=5, n_anchors=9, n_classes=7):
+    """VGG16 variant (vgg16.py:29-124 layer names: blockB_convI, fc1, fc2, rpn_*, dense_*); fc1 alone is 411 MB."""
+    rs = np.random.RandomState(seed)
+    f = np.float32
+    W = {}
+    cin = 3
+    for b, n, ch in ((1, 2, 64), (2, 2, 128), (3, 3, 256), (4, 3, 512), (5, 3, 512)):
+        for i in range(1, n + 1):
+            name = "block%d_conv%d" % (b, i)
+            std = np.sqrt(2.0 / (9 * cin)) * (1.0 / 70.0 if name == "block1_conv1" else 1.0)
+            W[name] = {"kernel": (rs.standard_normal((3, 3, cin, ch)) * std).astype(f), "bias": (rs.standard_normal(ch) * 0.05).astype(f)}
+            cin = ch
+    W["rpn_conv1"] = {"kernel": (rs.standard_normal((3, 3, 512, 512)) * np.sqrt(2.0 / (9 * 512)) * 0.3).astype(f), "bias": (rs.standard_normal(512) * 0.05).astype(f)}
+    W["rpn_out_class"] = {"kernel": (rs.standard_normal((1, 1, 512, n_anchors)) * 0.03).astype(f), "bias": np.zeros(n_anchors, f)}
+    W["rpn_out_regress"] = {"kernel": (rs.standard_normal((1, 1, 512, 4 * n_anchors)) * 0.03).astype(f), "bias": np.zeros(4 * n_anchors, f)}
+    W["fc1"] = {"kernel": (rs.standard_normal((7 * 7 * 512, 4096)) * np.sqrt(2.0 / (7 * 7 * 512))).astype(f), "bias": (rs.standard_normal(4096) * 0.05).astype(f)}
+    W["fc2"] = {"kernel": (rs.standard_normal((4096, 4096)) * np.sqrt(2.0 / 4096)).astype(f), "bias": (rs.standard_normal(4096) * 0.05).astype(f)}
+    nreg = 4 * (n_classes - 1)
+    W["dense_class_%d" % n_classes] = {"kernel": (rs.standard_normal((4096, n_classes)) * 0.01).astype(f), "bias": (rs.standard_normal(n_classes) * 0.01).astype(f)}
+    W["dense_regress_%d" % n_classes] = {"kernel": (rs.standard_normal((4096, nreg)) * 0.01).astype(f), "bias": (rs.standard_normal(nreg) * 0.01).astype(f)}
+    return W
+
+
 def synthetic_panel(seed, height=600, width=1000):
     """uint8 BGR panel (cfg 2/4 panels are 600x1000, seed 1 + offsets)."""
     return np.random.RandomState(seed).randint(0, 256, (height, width, 3)).astype(np.uint8)

@@ -108,7 +108,7 @@ class TrainStep:
                                          cls=cls.copy(), sel_kept=list(sel_k)))
             hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
             eng.pack_roi_batch(P, sel, hp)
-            eng.head_forward(hp)
+            eng.head_forward(hp, training=True)
             eng.set_accumulate(hp["bwd"], n_head > 0)
             eng.head_backward(hp, accumulate=n_head > 0, loss_out=self._det_l[n_head])
             n_head += 1

@@ -1,0 +1,123 @@
+"""BASELINE config 5: VGG16 base_model swap, 3 anchor scales x 3 ratios, variable-N RoIs per image.
+Device path (radnet_hip.engine_vgg) vs the oracle (oracle/vgg.py, parity unpinned) on identical seeded inputs;
+Dropout masks are injected so both sides see the same ones.  fp32 tolerances as in test_gpu_engine.py."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def rel_err(a, b):
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from faster_rcnn.config import Config
+    from oracle import vgg
+    from radnet_hip import make_engine
+    C = Config()
+    C.network = "vgg16"
+    C.anchor_box_scales = [128, 256, 512]          # config.py:46: the original 3 scales -> A = 9
+    P = vgg.init_params(seed=5, n_anchors=9)
+    eng = make_engine(C)
+    eng.set_weights(P)
+    return C, P, eng
+
+
+def test_vgg_generators_agree():
+    from oracle import vgg
+    from radnet_hip import synth
+    a, b = vgg.init_params(seed=5), synth.synthetic_weights_vgg16(seed=5)
+    assert sorted(a) == sorted(b)
+    for n in a:
+        for k in a[n]:
+            assert np.array_equal(a[n][k], b[n][k]), (n, k)
+
+
+def test_vgg_rpn_forward_and_proposals(setup):
+    from oracle import dense, glue, vgg
+    C, P, eng = setup
+    assert eng.A == 9 and eng.feat_len(1000) == 62 and eng.feat_len(600) == 37
+    img = np.random.RandomState(0).randint(0, 256, (200, 328, 3)).astype(np.uint8)
+    F = vgg.base_forward(P, dense.preprocess_caffe_bgr(img))
+    p, r, _ = dense.rpn_forward(P, F)
+    bp = eng.upload_image(img)
+    Fg = eng.base_forward(bp)
+    rp = eng.rpn_forward(bp)
+    pred = rp["pred"].cpu().numpy()
+    assert tuple(Fg.shape) == F.shape == (1, 12, 20, 512)
+    assert rel_err(Fg.cpu().numpy(), F) < 1e-3
+    assert rel_err(pred[:, :9], p.reshape(-1, 9)) < 1e-3 and rel_err(pred[:, 9:45], r.reshape(-1, 36)) < 1e-3
+    R, Rn = eng.proposals(rp, 0.7, 300)
+    n = int(Rn.cpu()[0])
+    Rref = glue.rpn_to_roi(pred[:, :9].reshape(1, 12, 20, 9), pred[:, 9:45].reshape(1, 12, 20, 36), C, True, 300, 0.7)
+    assert n == len(Rref) and np.array_equal(R.cpu().numpy()[:n], Rref)
+
+
+@pytest.mark.parametrize("R", [5, 37, 120, 300])
+def test_vgg_head_variable_rois(setup, R):
+    """Variable-N RoIs (5 / 37 / 120 / 300): forward in inference mode and, for the small counts, the full
+    backward with injected dropout masks."""
+    from oracle import vgg
+    C, P, eng = setup
+    rs = np.random.RandomState(R)
+    F = (np.maximum(rs.standard_normal((1, 37, 62, 512)), 0) * 2).astype(np.float32)
+    rois = np.stack([rs.randint(0, 50, R), rs.randint(0, 28, R), rs.randint(1, 12, R), rs.randint(1, 9, R)], 1).astype(np.float32)
+    Fd = torch.from_numpy(F).cuda()
+    hp = eng._plan_head(R, 37, 62, Fd)
+    hp["rois"].copy_(torch.from_numpy(rois))
+    eng.head_forward(hp, training=False)
+    pc, pr, cache = vgg.head_forward(P, F, rois, 7, None)
+    assert rel_err(hp["h1"].cpu().numpy(), cache["h1"]) < 1e-3
+    assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 2e-3 and rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 2e-3
+    if R > 40:
+        return
+    cls = rs.randint(0, 7, R)
+    Y1 = np.eye(7, dtype=np.float32)[cls][None]
+    lab = np.zeros((R, 24), np.float32)
+    for i, c in enumerate(cls):
+        if c != 6:
+            lab[i, 4 * c:4 * c + 4] = 1
+    Y2 = np.concatenate([lab, rs.standard_normal((R, 24)).astype(np.float32) * lab], -1)[None]
+    m1 = (rs.uniform(size=(R, 4096)) >= 0.5).astype(np.float32) * 2
+    m2 = (rs.uniform(size=(R, 4096)) >= 0.5).astype(np.float32) * 2
+    losses, grads = vgg.head_losses_and_grads(P, F, rois, Y1, Y2, 7, (m1, m2))
+    hp["y1"].copy_(torch.from_numpy(Y1[0])); hp["y2"].copy_(torch.from_numpy(Y2[0]))
+    eng.forced_masks = (m1, m2)
+    eng.head_forward(hp, training=True)
+    eng.set_accumulate(hp["bwd"], False)
+    eng.head_backward(hp, accumulate=False)
+    eng.forced_masks = None
+    got = eng.det_losses.cpu().numpy()
+    assert abs(got[0] - losses[1]) < 2e-3 * abs(losses[1]) and abs(got[1] - losses[2]) < 2e-3 * abs(losses[2]) + 1e-6
+    for name in ("fc1", "fc2"):
+        c = eng.convs[name]
+        assert rel_err(c.dweight.cpu().numpy(), grads[name]["kernel"]) < 3e-3, name
+        assert rel_err(c.dbias.cpu().numpy(), grads[name]["bias"]) < 3e-3, name
+    dk = eng.dense_dw.cpu().numpy()
+    assert rel_err(dk[:, :7], grads["dense_class_7"]["kernel"]) < 3e-3
+    assert rel_err(dk[:, 7:31], grads["dense_regress_7"]["kernel"]) < 3e-3
+
+
+def test_vgg_train_step_runs_and_learns(setup):
+    """Whole iteration (train.py:288-402 order) on the VGG16 engine: finite losses, head step taken, and a second step
+    on the same batch lowers the RPN loss (dropout makes the head loss noisy, so only the RPN loss is asserted)."""
+    from radnet_hip import synth
+    from radnet_hip.trainer import TrainStep
+    C, P, eng = setup
+    eng.set_weights(copy.deepcopy(P))
+    C.img_size = 300
+    img = synth.synthetic_panel(1, 300, 500)
+    meta = synth.synthetic_gt(2, n=6, src_w=1000, src_h=600, smin=60, smax=300)
+    sample = dict(img=img, bboxes=meta["bboxes"], width=1000, height=600)
+    np.random.seed(64)
+    ts = TrainStep(eng)
+    l0 = ts.step([sample]).losses()
+    l1 = ts.step([sample]).losses()
+    assert l0["n_head"] == 1 and all(np.isfinite(v) for v in l0.values())
+    assert l1["rpn_cls"] + l1["rpn_regr"] < l0["rpn_cls"] + l0["rpn_regr"]
