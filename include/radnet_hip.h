@@ -46,6 +46,9 @@ int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);
  * tunes the whole layer program.  radnet_tuned_shapes() returns the number of cached shapes. */
 int radnet_set_autotune(radnet_ctx* ctx, int enable);
 int radnet_tuned_shapes(radnet_ctx* ctx);
+/* Test hook: force every following conv GEMM launch to use output tile (tile_a x tile_b in {64,128}) and `slices` K
+ * slices per tile (negative = same slices with the XCD-aware workgroup order); tile_a = 0 switches it off. */
+int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);
 /* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
  * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
  * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd,1 dgrad,2 wgrad). */
@@ -85,7 +88,7 @@ typedef struct radnet_conv_desc {
   const float* dx_mask;  /* dx zeroed where dx_mask <= 0 (producer's ReLU) or 0            */
   float* dw;             /* wgrad output [kh*kw*c][ldw]                                    */
   int32_t ld_dy, ld_dx, ld_dx_add, ld_dx_mask;
-  int32_t dw_accumulate; /* 1: dw += (buffer pre-zeroed / holds other contributions)       */
+  int32_t dw_accumulate; /* 0: overwrite dw; 1: dw += ; 2: dw was zeroed by the caller (no memset, no atomics unless split) */
 } radnet_conv_desc;
 
 int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d);

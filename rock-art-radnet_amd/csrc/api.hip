@@ -26,6 +26,10 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
     (void)hipEventDestroy(ctx->pend0[i]);
     (void)hipEventDestroy(ctx->pend1[i]);
   }
+  for (auto& kv : ctx->unit_tables) {
+    if (kv.second.d_units) (void)hipFree(kv.second.d_units);
+    if (kv.second.d_fix) (void)hipFree(kv.second.d_fix);
+  }
   if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
   if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
   delete ctx;
@@ -46,6 +50,16 @@ extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
 }
 
 extern "C" int radnet_tuned_shapes(radnet_ctx* ctx) { return ctx ? (int)ctx->tuned.size() : -1; }
+
+extern "C" int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices) {
+  if (!ctx) return RADNET_ERR_ARG;
+  if (tile_a != 0 && ((tile_a != 64 && tile_a != 128) || (tile_b != 64 && tile_b != 128)))
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "force_config: tiles must be 64 or 128");
+  ctx->force_a = tile_a;
+  ctx->force_b = tile_b;
+  ctx->force_splits = slices;
+  return RADNET_OK;
+}
 
 extern "C" int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes) {
   if (!ctx) return RADNET_ERR_ARG;

@@ -50,7 +50,7 @@ struct GemmArgs {
   int act, act_cols;
   int flip;              // dgrad: kernel position flipped (npos-1-pos)
   int cin_fwd;           // dgrad B addressing: forward input channels (= N here)
-  int kt_per_split;      // K tiles per split
+  const int* units;      // work-unit table (8 ints per unit: tile_m, tile_n, kt_begin, kt_end, slot, pad..) or null
   unsigned long long magic_ohow, magic_ow;
   int OHOW;
   unsigned x_bytes, w_bytes;   // extents for the buffer descriptors
@@ -63,7 +63,9 @@ __device__ __forceinline__ int div_magic(int m, unsigned long long magic) {
 // Buffer loads: the 128-bit resource descriptor carries the tensor's byte size, and the hardware returns 0 for
 // any offset beyond it.  Padding taps, rows past M and columns past N are therefore expressed as the offset
 // kOOB instead of a branch: all of a tile's loads issue back to back and are waited for once, at the LDS store.
-constexpr unsigned kOOB = 0xFFFFFFFFu;
+// 2^31, not 2^32-1: every descriptor here covers < 2 GiB (checked by the launchers), so offset + 16 can neither
+// wrap around in 32-bit range arithmetic nor fall inside the buffer.
+constexpr unsigned kOOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
@@ -133,8 +135,17 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int split = blockIdx.z;
+  // Work assignment.  Plain launch: one workgroup per output tile.  Unit-table launch (g.units != null): the host
+  // cut the linearised (tile, k-tile) iteration space into near-equal chunks so every CU gets the same amount of
+  // MFMA work whatever the tile count (stream-K style); a unit is (tile, k range, partial slot or -1).
+  int m0, n0, unit_kb = 0, unit_ke = 0, slot = -1;
+  if (g.units != nullptr) {
+    const int4 u0 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x];
+    const int4 u1 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x + 1];
+    m0 = u0.x * BM; n0 = u0.y * BN; unit_kb = u0.z; unit_ke = u0.w; slot = u1.x;
+  } else {
+    m0 = blockIdx.x * BM; n0 = blockIdx.y * BN;
+  }
 
   // ---- per-thread A rows: decode m -> (image, oh, ow) once
   const int a_kc = tid & 7;
@@ -158,9 +169,8 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   }
 
   const int nk_total = (g.K + BK - 1) / BK;
-  const int kt_begin = split * g.kt_per_split;
-  int kt_end = kt_begin + g.kt_per_split;
-  if (kt_end > nk_total) kt_end = nk_total;
+  const int kt_begin = g.units != nullptr ? unit_kb : 0;
+  const int kt_end = g.units != nullptr ? unit_ke : nk_total;
 
   // running position of the current K tile: (pos, ci0) with k0 = pos*C + ci0
   int pos = 0, ci0 = 0;
@@ -172,10 +182,18 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w, g.w_bytes);
-  float4 ra[A_ITERS], rb[B_ITERS];
-  float4 rs = make_float4(1, 1, 1, 1);
+  // Two register stages: the loads of tile t+2 are issued while tile t is being multiplied and tile t+1 waits in the
+  // other stage, so a memory round trip (1-2 us when the line comes from the Infinity Cache or HBM) has TWO tile
+  // times to complete.  With one stage the short-K layers (8 K tiles per workgroup, 2-3 waves per SIMD) were bound
+  // by that latency, not by the matrix cores.
+  struct Stage {
+    float4 a[A_ITERS], b[B_ITERS], s;
+  };
+  Stage st0, st1;
+  st0.s = make_float4(1, 1, 1, 1);
+  st1.s = make_float4(1, 1, 1, 1);
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, Stage& st) {
     // ---------------- A: implicit im2col gather (branch-free: invalid taps load from kOOB -> 0)
     if (SMALLC) {
       const int p = kt * 8 + a_kc;           // kernel position of this thread's chunk
@@ -185,21 +203,21 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       for (int i = 0; i < A_ITERS; ++i) {
         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
         const bool ok = pv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-        ra[i] = buf_load4(rx, ok ? (unsigned)(a_pix[i] + ih * g.W + iw) * 16u : kOOB);
+        st.a[i] = buf_load4(rx, ok ? (unsigned)(a_pix[i] + ih * g.W + iw) * 16u : kOOB);
       }
     } else {
       const int kh = pos / g.KW, kw = pos - kh * g.KW;
       const int ci = ci0 + a_kc * 4;
       const bool kv = (pos * g.C + ci) < g.K;
       if (g.in_scale != nullptr) {
-        rs = make_float4(0, 0, 0, 0);
-        if (kv) rs = *reinterpret_cast<const float4*>(g.in_scale + ci);
+        st.s = make_float4(0, 0, 0, 0);
+        if (kv) st.s = *reinterpret_cast<const float4*>(g.in_scale + ci);
       }
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
         const bool ok = kv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-        ra[i] = buf_load4(rx, ok ? ((unsigned)(a_pix[i] + ih * g.W + iw) * (unsigned)g.C + (unsigned)ci) * 4u : kOOB);
+        st.a[i] = buf_load4(rx, ok ? ((unsigned)(a_pix[i] + ih * g.W + iw) * (unsigned)g.C + (unsigned)ci) * 4u : kOOB);
       }
     }
     // ---------------- B
@@ -211,7 +229,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
         const int kr = c / CPR, n4 = c - kr * CPR;
         const int k = kt * BK + kr, n = n0 + n4 * 4;
         const bool ok = (k < g.K) & (n < g.N);  // N is a multiple of 4 (launcher checks)
-        rb[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
+        st.b[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
       }
     } else {
       const int fpos = g.flip ? (g.npos - 1 - pos) : pos;
@@ -221,7 +239,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       for (int i = 0; i < B_ITERS; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
         const bool ok = kv & (n < g.N);
-        rb[i] = buf_load4(rw, ok ? (((unsigned)fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)co) * 4u : kOOB);
+        st.b[i] = buf_load4(rw, ok ? (((unsigned)fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)co) * 4u : kOOB);
       }
     }
     if (!SMALLC) {
@@ -230,13 +248,13 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const Stage& st) {
     float* sA = sA0 + buf * BK * PA;
     float* sB = sB0 + buf * BK * PB;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      float4 v = ra[i];
-      v.x *= rs.x; v.y *= rs.y; v.z *= rs.z; v.w *= rs.w;
+      float4 v = st.a[i];
+      v.x *= st.s.x; v.y *= st.s.y; v.z *= st.s.z; v.w *= st.s.w;
       store_trans(sA, PA, (tid >> 3) + 32 * i, a_kc, v);
     }
     if (BMODE == 0) {
@@ -245,11 +263,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       for (int i = 0; i < B_ITERS; ++i) {
         const int c = tid + NTHREADS * i;
         const int kr = c / CPR, n4 = c - kr * CPR;
-        *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = rb[i];
+        *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = st.b[i];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) store_trans(sB, PB, (tid >> 3) + 32 * i, a_kc, rb[i]);
+      for (int i = 0; i < B_ITERS; ++i) store_trans(sB, PB, (tid >> 3) + 32 * i, a_kc, st.b[i]);
     }
   };
 
@@ -262,23 +280,41 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
+    load_tile(kt_begin, st0);
+    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, st1);
+    store_tile(0, st0);
     __syncthreads();
     const int a_off = hi * PA + wm * (BM / 2) + l31;
     const int b_off = hi * PB + wn * (BN / 2) + l31;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int buf = (kt - kt_begin) & 1;
-      const bool more = kt + 1 < kt_end;
-      if (more) load_tile(kt + 1);
+    // invariant at the top of step(kt, cur): LDS buffer cur holds tile kt; stage `nxt` holds tile kt+1 (in flight or
+    // landed); stage `cur` is free
+    auto step = [&](int kt, int buf, Stage& cur, Stage& nxt) {
+      if (kt + 2 < kt_end) load_tile(kt + 2, cur);
       mfma_tile<TM, TN>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, acc);
-      if (more) store_tile(buf ^ 1);
+      if (kt + 1 < kt_end) store_tile(buf ^ 1, nxt);
       __syncthreads();
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      step(kt, 0, st0, st1);
+      if (kt + 1 < kt_end) step(kt + 1, 1, st1, st0);
     }
   }
 
   // ---- epilogue: accumulator register r of a 32x32 tile = row (r&3)+8*(r>>2)+4*hi, column lane&31
-  const bool direct = g.partial == nullptr;
+  const bool direct = slot < 0;
+  if (!direct) {
+    // partial sums of a K-split tile: dense BM x BN slab number `slot` in the workspace (no bounds: rows past M
+    // accumulated zeros), summed in slot order by splitk_fixup_kernel
+    float* slab = g.partial + (size_t)slot * (BM * BN);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -295,16 +331,12 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
         const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (nv && m < g.M) {
           float v = acc[i][j][r];
-          if (direct) {
-            v = v * sc + sh;
-            if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
-            if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
-            if (g.act == 1) v = fmaxf(v, 0.f);
-            else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
-            g.y[(size_t)m * g.ldy + n] = v;
-          } else {
-            g.partial[((size_t)split * g.M + m) * g.N + n] = v;
-          }
+          v = v * sc + sh;
+          if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+          if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+          if (g.act == 1) v = fmaxf(v, 0.f);
+          else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
+          g.y[(size_t)m * g.ldy + n] = v;
         }
       }
     }
@@ -312,15 +344,20 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 }
 
 // ---- split-K reduction + epilogue ------------------------------------------------------------------
-__global__ void __launch_bounds__(256) splitk_epilogue_kernel(GemmArgs g, int splits) {
-  const int n4 = g.N >> 2;
-  const long long total = (long long)g.M * n4;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(idx / n4);
-    const int n = (int)(idx - (long long)m * n4) * 4;
+// One workgroup per K-split tile: fix[4*b] = {tile_m, tile_n, first_slot, n_slots}.  Slabs are summed in slot
+// (= k) order, so the result does not depend on which workgroup finished first.
+__global__ void __launch_bounds__(256) splitk_fixup_kernel(GemmArgs g, const int* __restrict__ fix, int bm, int bn) {
+  const int4 f = reinterpret_cast<const int4*>(fix)[blockIdx.x];
+  const int m0 = f.x * bm, n0 = f.y * bn;
+  const float* slab0 = g.partial + (size_t)f.z * (bm * bn);
+  const int bn4 = bn >> 2;
+  for (int e = threadIdx.x; e < bm * bn4; e += blockDim.x) {
+    const int r = e / bn4, c = (e - r * bn4) * 4;
+    const int m = m0 + r, n = n0 + c;
+    if (m >= g.M || n >= g.N) continue;
     float4 s = make_float4(0, 0, 0, 0);
-    for (int k = 0; k < splits; ++k) {
-      float4 p = *reinterpret_cast<const float4*>(g.partial + ((size_t)k * g.M + m) * g.N + n);
+    for (int k = 0; k < f.w; ++k) {
+      const float4 p = *reinterpret_cast<const float4*>(slab0 + (size_t)k * (bm * bn) + r * bn + c);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     float v[4] = {s.x, s.y, s.z, s.w};
@@ -333,8 +370,9 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(GemmArgs g, int sp
       if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n + q] > 0.f)) t = 0.f;
       if (g.act == 1) t = fmaxf(t, 0.f);
       else if (g.act == 2 && n + q < g.act_cols) t = 1.f / (1.f + __expf(-t));
-      g.y[(size_t)m * g.ldy + n + q] = t;
+      v[q] = t;
     }
+    *reinterpret_cast<float4*>(g.y + (size_t)m * g.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -508,10 +546,73 @@ TileChoice choose_tiles(int M, int N, int K, bool allow_split) {
   return best;
 }
 
+// Work-unit table for a K-split launch (host side of the stream-K style partition).  The (tile, k-tile) iteration
+// space, tiles in row-major order, is cut into `chunks` equal ranges; a unit is the intersection of a range with a
+// tile.  Units covering a whole tile apply the epilogue themselves (slot -1); the others write a partial slab and
+// the tile is listed in the fix-up table.  Tables live in device memory owned by the context (cached per shape).
+radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, int bn, int chunks) {
+  const std::array<int, 6> key{M, N, K, bm, bn, chunks};
+  auto it = ctx->unit_tables.find(key);
+  if (it != ctx->unit_tables.end()) return &it->second;
+  const int Mt = radnet_cdiv(M, bm), Nt = radnet_cdiv(N, bn), nk = radnet_cdiv(K, BK);
+  const long long T = (long long)Mt * Nt, I = T * nk;
+  const long long L = (I + chunks - 1) / chunks;
+  std::vector<int> units, fix;
+  // Measured on MI355X: cutting the linearised iteration space into equal chunks (true stream-K) balances the CUs but
+  // lost 15-20 % against the uniform split below, because the order of the units decides what the XCD L2s can
+  // share: units that run together must read the SAME weight k-range (consecutive M tiles of one N tile and one
+  // k slice).  So: `chunks` = slices per tile, units ordered (slice, tile_n, tile_m) -- tile_m fastest.
+  (void)I; (void)L;
+  const int S = chunks < 0 ? -chunks : chunks, kt = radnet_cdiv(nk, S);
+  const int S_eff = radnet_cdiv(nk, kt);                      // no empty slice
+  int slots = (int)T * S_eff;
+  for (int s = 0; s < S_eff; ++s)
+    for (int tn = 0; tn < Nt; ++tn)
+      for (int tm = 0; tm < Mt; ++tm) {
+        const int tile = tn * Mt + tm;
+        const int u[8] = {tm, tn, s * kt, std::min(nk, (s + 1) * kt), S_eff > 1 ? tile * S_eff + s : -1, 0, 0, 0};
+        units.insert(units.end(), u, u + 8);
+      }
+  if (S_eff > 1)
+    for (int tn = 0; tn < Nt; ++tn)
+      for (int tm = 0; tm < Mt; ++tm) {
+        const int f[4] = {tm, tn, (tn * Mt + tm) * S_eff, S_eff};
+        fix.insert(fix.end(), f, f + 4);
+      }
+  if (S_eff <= 1) slots = 0;
+  if (chunks < 0) {
+    // XCD-aware order (chunks < 0): the hardware deals workgroup b to XCD b % 8, each XCD has its own 4 MiB L2.
+    // Give every XCD a CONTIGUOUS run of the logical unit list, so the workgroups sharing one L2 are consecutive
+    // M tiles of one (slice, N tile) and read the same weight rows.  Bijective for any unit count.
+    const int U = (int)units.size() / 8, q = U / 8, r = U % 8;
+    std::vector<int> hw(units.size());
+    for (int b = 0; b < U; ++b) {
+      const int x = b % 8, j = b / 8;
+      const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+      std::copy(units.begin() + 8 * (size_t)(base + j), units.begin() + 8 * (size_t)(base + j) + 8, hw.begin() + 8 * (size_t)b);
+    }
+    units.swap(hw);
+  }
+  radnet_unit_table tb{};
+  tb.n_units = (int)units.size() / 8;
+  tb.n_fix = (int)fix.size() / 4;
+  tb.n_slots = slots;
+  if (hipMalloc(&tb.d_units, units.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(tb.d_units, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (tb.n_fix) {
+    if (hipMalloc(&tb.d_fix, fix.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(tb.d_fix, fix.data(), fix.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  }
+  auto ins = ctx->unit_tables.emplace(key, tb);
+  return &ins.first->second;
+}
+
 template <int BMODE, bool SMALLC>
-void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc) {
+void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n_units) {
   dim3 block(NTHREADS);
-  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), tc.splits);
+  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), 1);
+  if (g.units != nullptr) grid = dim3(n_units, 1, 1);
+  // (capping workgroups per CU with extra dynamic LDS was measured: 7-25 % slower on every layer -- co-residency wins)
   if (tc.bm == 128 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, BMODE, SMALLC>), grid, block, 0, st, g);
   else if (tc.bm == 128 && tc.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, BMODE, SMALLC>), grid, block, 0, st, g);
   else if (tc.bm == 64 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<64, 128, BMODE, SMALLC>), grid, block, 0, st, g);
@@ -534,27 +635,33 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.w_bytes = (unsigned)wb;
   }
   const int nk = radnet_cdiv(g.K, BK);
-  auto fits = [&](const TileChoice& t) {
-    if (t.splits > 1 && (uint64_t)t.splits * g.M * g.N * sizeof(float) > ctx->ws_bytes) return false;
-    if (t.splits > 1 && radnet_cdiv(nk, radnet_cdiv(nk, t.splits)) != t.splits) return false;   // no empty split
-    return true;
-  };
+  // TileChoice.splits = number of equal work chunks the iteration space is cut into (0/1 = one workgroup per tile)
   auto launch = [&](const TileChoice& t) -> int {
-    g.kt_per_split = radnet_cdiv(nk, t.splits);
-    g.partial = t.splits > 1 ? (float*)ctx->ws : nullptr;
+    radnet_unit_table* tb = nullptr;
+    g.units = nullptr;
+    g.partial = nullptr;
+    if (t.splits > 1 || t.splits < 0) {
+      tb = get_unit_table(ctx, g.M, g.N, g.K, t.bm, t.bn, t.splits);
+      if (!tb) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv: cannot build the work-unit table");
+      if ((uint64_t)tb->n_slots * t.bm * t.bn * sizeof(float) > ctx->ws_bytes) return RADNET_ERR_UNSUPPORTED;   // candidate skipped
+      if (tb->n_fix > 0 || t.splits < 0) {          // an un-split, un-swizzled table is just the plain launch
+        g.units = tb->d_units;
+        g.partial = (float*)ctx->ws;
+      } else {
+        tb = nullptr;
+      }
+    }
+    const int n_units = tb ? tb->n_units : 0;
     if (bmode == 0) {
-      if (smallc) launch_igemm<0, true>(ctx->stream, g, t);
-      else launch_igemm<0, false>(ctx->stream, g, t);
+      if (smallc) launch_igemm<0, true>(ctx->stream, g, t, n_units);
+      else launch_igemm<0, false>(ctx->stream, g, t, n_units);
     } else {
-      launch_igemm<1, false>(ctx->stream, g, t);
+      launch_igemm<1, false>(ctx->stream, g, t, n_units);
     }
     RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
-    if (t.splits > 1) {
-      const long long total = (long long)g.M * (g.N >> 2);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g, t.splits);
-      RADNET_CHECK_LAUNCH(ctx, "splitk_epilogue");
+    if (tb && tb->n_fix > 0) {
+      hipLaunchKernelGGL(splitk_fixup_kernel, dim3(tb->n_fix), dim3(256), 0, ctx->stream, g, (const int*)tb->d_fix, t.bm, t.bn);
+      RADNET_CHECK_LAUNCH(ctx, "splitk_fixup");
     }
     return RADNET_OK;
   };
@@ -562,27 +669,37 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   const radnet_shape_key key{cls == 1 ? 1 : 0, g.M, g.N, g.K, g.C, g.npos, g.stride};
   TileChoice tc{64, 64, 1};
   auto it = ctx->tuned.find(key);
-  if (it != ctx->tuned.end()) {
+  if (ctx->force_a > 0) {                      // radnet_force_config: tests sweep every tile / slice / order variant
+    tc = TileChoice{ctx->force_a, ctx->force_b, ctx->force_splits};
+    if (tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
+  } else if (it != ctx->tuned.end()) {
     tc = TileChoice{it->second.a, it->second.b, it->second.splits};
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    const int splits[] = {1, 2, 3, 4, 5, 6, 8, 12};
+    const int chunks[] = {1, 2, 3, 4, 5, 6, 8, 12};                 // K slices per tile
     float best = 1e30f;
     for (int c = 0; c < 4; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
-      for (int s : splits) {
-        TileChoice t{cand[c][0], cand[c][1], s};
-        if ((s > 1 && nk / s < 4) || !fits(t)) continue;
-        float ms = 0.f;
-        int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
-        if (rc != RADNET_OK) return rc;
-        if (ms < best) { best = ms; tc = t; }
+      const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
+      for (int s : chunks) {
+        if (s > 1 && (ctx->ws == nullptr || nk / s < 4)) continue;              // slices shorter than 4 k-tiles
+        for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
+          if (sign < 0 && tiles * s < 16) continue;
+          TileChoice t{cand[c][0], cand[c][1], sign * s};
+          float ms = 0.f;
+          int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
+          if (rc == RADNET_ERR_UNSUPPORTED) continue;
+          if (rc != RADNET_OK) return rc;
+          if (ms < best) { best = ms; tc = t; }
+        }
       }
     }
     ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best};
+    if (getenv("RADNET_TUNE_LOG"))
+      fprintf(stderr, "[radnet tune] %s M=%d N=%d K=%d C=%d -> tile %dx%d chunks %d : %.1f us (%.1f TFLOP/s)\n", cls == 1 ? "dgrad" : "fwd", g.M,
+              g.N, g.K, g.C, tc.bm, tc.bn, tc.splits, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
   } else {
     tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
-    if (!fits(tc)) tc.splits = 1;
   }
   radnet_timing_begin(ctx);
   int rc = launch(tc);
@@ -654,8 +771,10 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   const int nmt = radnet_cdiv(g.M, BK);
   auto launch = [&](int bmk, int bn, int splits) -> int {
     g.mt_per_split = radnet_cdiv(nmt, splits);
-    g.atomic = (splits > 1 || d->dw_accumulate) ? 1 : 0;
-    if (splits > 1 && !d->dw_accumulate)      // atomics need a zeroed destination
+    // dw_accumulate: 0 = overwrite, 1 = add to existing contents, 2 = destination is pre-zeroed by the caller
+    // (plain stores when un-split, atomics without the memset when split)
+    g.atomic = (splits > 1 || d->dw_accumulate == 1) ? 1 : 0;
+    if (splits > 1 && d->dw_accumulate == 0)  // atomics need a zeroed destination
       RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
     dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits), block(NTHREADS);
     if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
@@ -666,11 +785,14 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
     return RADNET_OK;
   };
   int bmk = (d->c % 128 == 0) ? 128 : 64, bn = g.N > 64 ? 128 : 64, splits = 1;
-  const radnet_shape_key key{2 + (d->dw_accumulate ? 1 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
+  const radnet_shape_key key{2 + (d->dw_accumulate == 1 ? 1 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
   auto it = ctx->tuned.find(key);
-  if (it != ctx->tuned.end()) {
+  if (ctx->force_a > 0) {
+    bmk = ctx->force_a; bn = ctx->force_b; splits = ctx->force_splits < 1 ? 1 : ctx->force_splits;
+    if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced k tile %d does not divide c=%d", bmk, d->c);
+  } else if (it != ctx->tuned.end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
-  } else if (ctx->autotune && !d->dw_accumulate) {
+  } else if (ctx->autotune && d->dw_accumulate != 1) {
     float best = 1e30f;
     for (int cb = 128; cb >= 64; cb -= 64) {
       if (d->c % cb) continue;
@@ -686,6 +808,11 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
       }
     }
     ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best};
+    if (getenv("RADNET_TUNE_LOG"))
+      fprintf(stderr, "radnet tune: wgrad M=%d N=%d K=%d C=%d -> tile %dx%d slices %d : %.1f us (%.1f TFLOP/s)\n", g.M, g.N, g.K, g.C,
+              bmk, bn, splits, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
+    if (d->dw_accumulate == 2)               // the trial launches added into the pre-zeroed buffer: restore it
+      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
   } else {
     // accumulate mode reuses the overwrite-mode measurement when there is one
     const radnet_shape_key k0{2, g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};

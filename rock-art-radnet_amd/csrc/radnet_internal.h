@@ -3,10 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <array>
 #include <map>
 #include <tuple>
+#include <utility>
+#include <vector>
 
 #include "radnet_hip.h"
 
@@ -28,9 +33,18 @@ struct radnet_tuned {
   float ms;
 };
 
+// Device-resident work-unit / fix-up tables of a K-split GEMM launch (conv_mfma.hip: get_unit_table).
+struct radnet_unit_table {
+  int* d_units = nullptr;
+  int* d_fix = nullptr;
+  int n_units = 0, n_fix = 0, n_slots = 0;
+};
+
 struct radnet_ctx {
   int autotune = 0;
+  int force_a = 0, force_b = 0, force_splits = 0;      // radnet_force_config (tests): overrides tuned / heuristic choices
   std::map<radnet_shape_key, radnet_tuned> tuned;
+  std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
   hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;

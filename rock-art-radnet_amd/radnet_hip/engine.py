@@ -362,14 +362,16 @@ class FasterRCNNEngine:
                 self.ctx.check(rc, kind)
 
     @staticmethod
-    def set_accumulate(ops, flag, dense=None):
-        """First image of a mini-batch overwrites the gradient arena (no memset needed), later ones add."""
-        v = 1 if flag else 0
+    def set_accumulate(ops, flag, prezeroed=False):
+        """Gradient write mode of a backward program: flag=False -> overwrite (self-contained; each split wgrad /
+        colsum zeroes its own slice), flag=True -> add.  prezeroed=True with flag=False: the caller zeroed the whole
+        arena with ONE memset, so the ~25 per-layer memsets disappear (dw_accumulate = 2)."""
+        v = 1 if flag else (2 if prezeroed else 0)
         for kind, p in ops:
             if kind == "wgrad":
                 p.dw_accumulate = v
             elif kind == "colsum":
-                p[6] = v
+                p[6] = 1 if (flag or prezeroed) else 0
 
     # ------------------------------------------------------------------------------------------ forward pieces
     def upload_image(self, img_bgr_u8, slot=0):

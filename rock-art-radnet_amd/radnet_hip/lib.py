@@ -68,6 +68,7 @@ def load_library():
         "radnet_set_workspace": (C.c_int, [vp, vp, u64]),
         "radnet_set_autotune": (C.c_int, [vp, C.c_int]),
         "radnet_tuned_shapes": (C.c_int, [vp]),
+        "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
         "radnet_timing_reset": (C.c_int, [vp]),

@@ -93,7 +93,6 @@ def test_head_forward_backward(setup):
         if c != 6:
             lab[i, 4 * c:4 * c + 4] = 1
     Y2 = np.concatenate([lab, rs.standard_normal((R, 24)).astype(np.float32) * lab], -1)[None]
-    losses, grads = dense.head_losses_and_grads(P, F, rois, Y1, Y2, 7)
     Fd = torch.from_numpy(F).cuda()
     hp = eng._plan_head(R, 20, 31, Fd)
     hp["rois"].copy_(torch.from_numpy(rois)); hp["y1"].copy_(torch.from_numpy(Y1[0])); hp["y2"].copy_(torch.from_numpy(Y2[0]))
@@ -102,6 +101,23 @@ def test_head_forward_backward(setup):
     assert rel_err(hp["feat"].cpu().numpy(), cache["feat"]) < 1e-3
     assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 1e-3
     assert rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 1e-3
+    # ReLU ties: among ~10^6 activations a pre-activation can land within fp32 rounding of 0, positive in one
+    # summation order and negative in another (which order runs depends on the launch configuration the autotuner
+    # measured fastest).  The backward mask of such an element is then legitimately different; take the mask from
+    # the GPU's activation there -- and only there: the values must agree to 1e-5 and the count must stay tiny.
+    ties = 0
+    for B, cb in zip(hp["blocks"], cache["blocks"]):
+        for gk, ok in (("a", "a"), ("b", "b"), ("out", "c")):
+            g, r = B[gk].cpu().numpy().reshape(cb[ok]["y"].shape), cb[ok]["y"]
+            flip = (g > 0) != (r > 0)
+            assert np.abs(g - r)[flip].max(initial=0.0) <= 1e-5 * np.abs(r).max()
+            r[flip] = g[flip]
+            ties += int(flip.sum())
+    assert ties <= 8
+    l_cls, dpc = dense.class_loss_cls(Y1, pc)
+    l_regr, dpr = dense.smooth_l1_masked(Y2, pr, 24)
+    grads, _ = dense.head_backward(P, cache, dpc, dpr)
+    losses = [l_cls + l_regr, l_cls, l_regr, dense.categorical_accuracy(Y1, pc)]
     eng.set_accumulate(hp["bwd"], False)
     eng.head_backward(hp, accumulate=False)
     got = eng.det_losses.cpu().numpy()
