@@ -28,7 +28,7 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
   }
   for (auto& kv : ctx->unit_tables) {
     if (kv.second.d_units) (void)hipFree(kv.second.d_units);
-    if (kv.second.d_fix) (void)hipFree(kv.second.d_fix);
+    if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
   }
   if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
   if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);

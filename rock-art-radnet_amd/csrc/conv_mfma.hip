@@ -54,7 +54,16 @@ struct GemmArgs {
   unsigned long long magic_ohow, magic_ow;
   int OHOW;
   unsigned x_bytes, w_bytes;   // extents for the buffer descriptors
+  unsigned y_bytes, add_bytes, mask_bytes;
+  unsigned* counters;          // K-split launches: arrival counter per output tile (zero outside a launch)
+  unsigned long long* stamps;  // diagnostic build only (RADNET_DIAG_STAMPS): 8 words per workgroup
 };
+
+#ifdef RADNET_DIAG_STAMPS
+#define RADNET_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define RADNET_STAMP(var)
+#endif
 
 __device__ __forceinline__ int div_magic(int m, unsigned long long magic) {
   return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
@@ -72,6 +81,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
   f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
   return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+// sc1 (aux 16): write-through store / L1-bypassing agent-coherent load, for data handed to another workgroup in-launch
+__device__ __forceinline__ float buf_load1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 16));
+}
+__device__ __forceinline__ void buf_store1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 16);
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
 }
 
 // ---- operand staging -----------------------------------------------------------------------------
@@ -131,6 +153,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   float* sA0 = lds;
   float* sB0 = lds + 2 * BK * PA;
 
+  RADNET_STAMP(t_start);
+#ifdef RADNET_DIAG_STAMPS
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_first = t_start, t_loop = t_start;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -138,11 +165,12 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   // Work assignment.  Plain launch: one workgroup per output tile.  Unit-table launch (g.units != null): the host
   // cut the linearised (tile, k-tile) iteration space into near-equal chunks so every CU gets the same amount of
   // MFMA work whatever the tile count (stream-K style); a unit is (tile, k range, partial slot or -1).
-  int m0, n0, unit_kb = 0, unit_ke = 0, slot = -1;
+  int m0, n0, unit_kb = 0, unit_ke = 0, slot = -1, slot0 = 0, n_slices = 1, tile_id = 0;
   if (g.units != nullptr) {
     const int4 u0 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x];
     const int4 u1 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x + 1];
-    m0 = u0.x * BM; n0 = u0.y * BN; unit_kb = u0.z; unit_ke = u0.w; slot = u1.x;
+    m0 = u0.x * BM; n0 = u0.y * BN; unit_kb = u0.z; unit_ke = u0.w;
+    slot = u1.x; slot0 = u1.y; n_slices = u1.z; tile_id = u1.w;
   } else {
     m0 = blockIdx.x * BM; n0 = blockIdx.y * BN;
   }
@@ -284,6 +312,9 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, st1);
     store_tile(0, st0);
     __syncthreads();
+#ifdef RADNET_DIAG_STAMPS
+    t_first = __builtin_amdgcn_s_memtime();
+#endif
     const int a_off = hi * PA + wm * (BM / 2) + l31;
     const int b_off = hi * PB + wn * (BN / 2) + l31;
     // invariant at the top of step(kt, cur): LDS buffer cur holds tile kt; stage `nxt` holds tile kt+1 (in flight or
@@ -299,81 +330,121 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       if (kt + 1 < kt_end) step(kt + 1, 1, st1, st0);
     }
   }
+#ifdef RADNET_DIAG_STAMPS
+  t_loop = __builtin_amdgcn_s_memtime();
+  // stamps go to a buffer of their own; nothing the kernel outputs is computed from them.  The epilogue stamp is
+  // taken by a trailing block below (after the stores have been ISSUED, plus a vmcnt(0) wait so it covers their
+  // completion).
+  auto write_stamps = [&]() {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (g.stamps != nullptr && tid == 0) {
+      unsigned long long* s = g.stamps + 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+      s[0] = t_start; s[1] = t_first; s[2] = t_loop; s[3] = t_end;
+      s[4] = rt_start; s[5] = __builtin_amdgcn_s_memrealtime();
+      s[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+      s[7] = (unsigned long long)(kt_end - kt_begin);
+    }
+  };
+#endif
 
   // ---- epilogue: accumulator register r of a 32x32 tile = row (r&3)+8*(r>>2)+4*hi, column lane&31
-  const bool direct = slot < 0;
-  if (!direct) {
-    // partial sums of a K-split tile: dense BM x BN slab number `slot` in the workspace (no bounds: rows past M
-    // accumulated zeros), summed in slot order by splitk_fixup_kernel
-    float* slab = g.partial + (size_t)slot * (BM * BN);
+  if (slot >= 0) {
+    // K-split tile: every slice writes its partial sums as a dense BM x BN slab (no bounds: rows past M accumulated
+    // zeros), then takes a ticket from the tile's arrival counter; the slice that draws the last ticket sums ALL
+    // slabs in slot (= k) order -- its own included, read back from memory, so the result does not depend on who
+    // arrived last -- and applies the epilogue.  Hand-off = cdna_hip_programming.md 6 Guideline 16 R1 / 5 'In-launch
+    // split-K reduction', write-through form: every slab store carries sc1 and is drained (vmcnt(0)) by its wave
+    // before the barrier, one lane takes the relaxed agent-scope ticket, and EVERY slab load of the reducer is an
+    // sc1 load -- no release / acquire cache maintenance (the plain-store + fence form cost 5-12 us per workgroup
+    // here: each release writes back the XCD's whole L2).  Correct for any placement of the slices on XCDs / CUs.
+    const unsigned lane_off = (unsigned)((wm * (BM / 2) + 4 * hi) * BN + wn * (BN / 2) + l31) * 4u;
+    const __amdgpu_buffer_rsrc_t rslab = make_rsrc(g.partial + (size_t)slot * (BM * BN), BM * BN * 4u);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          slab[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
-    return;
+          buf_store1_sc1(rslab, lane_off + (unsigned)((i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32) * 4u, acc[i][j][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    volatile int* flag = reinterpret_cast<volatile int*>(lds);      // the staging array is free after the K loop
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(g.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(n_slices - 1);
+      if (last) __hip_atomic_store(g.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0] == 0) {
+#ifdef RADNET_DIAG_STAMPS
+      write_stamps();
+#endif
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // compiler-only: keeps the slab loads below the ticket
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < n_slices; ++s) {
+      const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g.partial + (size_t)(slot0 + s) * (BM * BN), BM * BN * 4u);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += buf_load1_sc1(rsrc, lane_off + (unsigned)((i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32) * 4u);
+    }
   }
+  // Branch-free like the operand loads: rows past M / columns past N get the offset kOOB, which the hardware answers
+  // with 0 for loads and drops for stores.  All 16 residual (and mask) loads of a 32x32 tile are issued back to back
+  // before the first store, so their latency is paid once per tile instead of once per register (a conditional
+  // load -> store chain cannot be reordered by the compiler: y may alias the addend).
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(g.y, g.y_bytes);
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(g.addend, g.addend ? g.add_bytes : 0u);     // null -> every load returns 0
+  const __amdgpu_buffer_rsrc_t rmask = make_rsrc(g.mask, g.mask ? g.mask_bytes : 0u);
+  const bool has_mask = g.mask != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
     const bool nv = n < g.N;
     float sc = 1.f, sh = 0.f;
-    if (direct && nv) {
+    if (nv) {
       if (g.scale) sc = g.scale[n];
       if (g.shift) sh = g.shift[n];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * hi;
+      float ad[16], mk[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (nv && m < g.M) {
-          float v = acc[i][j][r];
-          v = v * sc + sh;
-          if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
-          if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
-          g.y[(size_t)m * g.ldy + n] = v;
-        }
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const bool ok = nv & (m < g.M);
+        ad[r] = buf_load1(radd, ok ? ((unsigned)m * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB);
+        mk[r] = 1.f;
+        if (has_mask) mk[r] = buf_load1(rmask, ok ? ((unsigned)m * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const bool ok = nv & (m < g.M);
+        float v = acc[i][j][r] * sc + sh + ad[r];
+        if (!(mk[r] > 0.f)) v = 0.f;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
+        buf_store1(ry, ok ? ((unsigned)m * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB, v);
       }
     }
   }
-}
-
-// ---- split-K reduction + epilogue ------------------------------------------------------------------
-// One workgroup per K-split tile: fix[4*b] = {tile_m, tile_n, first_slot, n_slots}.  Slabs are summed in slot
-// (= k) order, so the result does not depend on which workgroup finished first.
-__global__ void __launch_bounds__(256) splitk_fixup_kernel(GemmArgs g, const int* __restrict__ fix, int bm, int bn) {
-  const int4 f = reinterpret_cast<const int4*>(fix)[blockIdx.x];
-  const int m0 = f.x * bm, n0 = f.y * bn;
-  const float* slab0 = g.partial + (size_t)f.z * (bm * bn);
-  const int bn4 = bn >> 2;
-  for (int e = threadIdx.x; e < bm * bn4; e += blockDim.x) {
-    const int r = e / bn4, c = (e - r * bn4) * 4;
-    const int m = m0 + r, n = n0 + c;
-    if (m >= g.M || n >= g.N) continue;
-    float4 s = make_float4(0, 0, 0, 0);
-    for (int k = 0; k < f.w; ++k) {
-      const float4 p = *reinterpret_cast<const float4*>(slab0 + (size_t)k * (bm * bn) + r * bn + c);
-      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-    }
-    float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float t = v[q];
-      if (g.scale) t *= g.scale[n + q];
-      if (g.shift) t += g.shift[n + q];
-      if (g.addend) t += g.addend[(size_t)m * g.ld_add + n + q];
-      if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n + q] > 0.f)) t = 0.f;
-      if (g.act == 1) t = fmaxf(t, 0.f);
-      else if (g.act == 2 && n + q < g.act_cols) t = 1.f / (1.f + __expf(-t));
-      v[q] = t;
-    }
-    *reinterpret_cast<float4*>(g.y + (size_t)m * g.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-  }
+#ifdef RADNET_DIAG_STAMPS
+  write_stamps();
+#endif
 }
 
 // ---- wgrad kernel -----------------------------------------------------------------------------------
@@ -546,23 +617,20 @@ TileChoice choose_tiles(int M, int N, int K, bool allow_split) {
   return best;
 }
 
-// Work-unit table for a K-split launch (host side of the stream-K style partition).  The (tile, k-tile) iteration
-// space, tiles in row-major order, is cut into `chunks` equal ranges; a unit is the intersection of a range with a
-// tile.  Units covering a whole tile apply the epilogue themselves (slot -1); the others write a partial slab and
-// the tile is listed in the fix-up table.  Tables live in device memory owned by the context (cached per shape).
+// Work-unit table for a K-split launch: a unit = (output tile, K slice).  Whole-tile units apply the epilogue
+// themselves (slot -1); the slices of a split tile write partial slabs and the last to arrive reduces them in the
+// same launch (arrival counter per tile).  Tables live in device memory owned by the context (cached per shape).
 radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, int bn, int chunks) {
   const std::array<int, 6> key{M, N, K, bm, bn, chunks};
   auto it = ctx->unit_tables.find(key);
   if (it != ctx->unit_tables.end()) return &it->second;
   const int Mt = radnet_cdiv(M, bm), Nt = radnet_cdiv(N, bn), nk = radnet_cdiv(K, BK);
-  const long long T = (long long)Mt * Nt, I = T * nk;
-  const long long L = (I + chunks - 1) / chunks;
-  std::vector<int> units, fix;
+  const long long T = (long long)Mt * Nt;
+  std::vector<int> units;
   // Measured on MI355X: cutting the linearised iteration space into equal chunks (true stream-K) balances the CUs but
   // lost 15-20 % against the uniform split below, because the order of the units decides what the XCD L2s can
   // share: units that run together must read the SAME weight k-range (consecutive M tiles of one N tile and one
   // k slice).  So: `chunks` = slices per tile, units ordered (slice, tile_n, tile_m) -- tile_m fastest.
-  (void)I; (void)L;
   const int S = chunks < 0 ? -chunks : chunks, kt = radnet_cdiv(nk, S);
   const int S_eff = radnet_cdiv(nk, kt);                      // no empty slice
   int slots = (int)T * S_eff;
@@ -570,14 +638,9 @@ radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, 
     for (int tn = 0; tn < Nt; ++tn)
       for (int tm = 0; tm < Mt; ++tm) {
         const int tile = tn * Mt + tm;
-        const int u[8] = {tm, tn, s * kt, std::min(nk, (s + 1) * kt), S_eff > 1 ? tile * S_eff + s : -1, 0, 0, 0};
+        // {tile_m, tile_n, kt_begin, kt_end | slot (-1 = whole tile, direct epilogue), first slot, slices, tile index}
+        const int u[8] = {tm, tn, s * kt, std::min(nk, (s + 1) * kt), S_eff > 1 ? tile * S_eff + s : -1, tile * S_eff, S_eff, tile};
         units.insert(units.end(), u, u + 8);
-      }
-  if (S_eff > 1)
-    for (int tn = 0; tn < Nt; ++tn)
-      for (int tm = 0; tm < Mt; ++tm) {
-        const int f[4] = {tm, tn, (tn * Mt + tm) * S_eff, S_eff};
-        fix.insert(fix.end(), f, f + 4);
       }
   if (S_eff <= 1) slots = 0;
   if (chunks < 0) {
@@ -595,13 +658,14 @@ radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, 
   }
   radnet_unit_table tb{};
   tb.n_units = (int)units.size() / 8;
-  tb.n_fix = (int)fix.size() / 4;
+  tb.n_split_tiles = S_eff > 1 ? (int)T : 0;
   tb.n_slots = slots;
   if (hipMalloc(&tb.d_units, units.size() * sizeof(int)) != hipSuccess) return nullptr;
   if (hipMemcpy(tb.d_units, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  if (tb.n_fix) {
-    if (hipMalloc(&tb.d_fix, fix.size() * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemcpy(tb.d_fix, fix.data(), fix.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (tb.n_split_tiles) {
+    // arrival counters: zeroed here once; every launch leaves them at zero again (the reducer resets its tile's)
+    if (hipMalloc(&tb.d_counters, (size_t)T * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(tb.d_counters, 0, (size_t)T * sizeof(unsigned)) != hipSuccess) return nullptr;
   }
   auto ins = ctx->unit_tables.emplace(key, tb);
   return &ins.first->second;
@@ -633,20 +697,31 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     if (xb >= (1ull << 31) || wb >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: tensor larger than 2 GiB");
     g.x_bytes = (unsigned)xb;
     g.w_bytes = (unsigned)wb;
+    const uint64_t ld_max = (uint64_t)std::max(g.ldy, std::max(g.addend ? g.ld_add : 0, g.mask ? g.ld_mask : 0));
+    if ((uint64_t)g.M * ld_max * 4ull >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: output larger than 2 GiB");
+    if (g.ldy < g.N || (g.addend && g.ld_add < g.N) || (g.mask && g.ld_mask < g.N))
+      RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: output / addend / mask row pitch smaller than n=%d", g.N);
+    // last row ends at column N, not at the pitch: the tensor may be a column block of a wider one
+    g.y_bytes = (unsigned)(((uint64_t)(g.M - 1) * g.ldy + g.N) * 4ull);
+    g.add_bytes = g.addend ? (unsigned)(((uint64_t)(g.M - 1) * g.ld_add + g.N) * 4ull) : 0u;
+    g.mask_bytes = g.mask ? (unsigned)(((uint64_t)(g.M - 1) * g.ld_mask + g.N) * 4ull) : 0u;
   }
+  g.stamps = ctx->diag_stamps;
   const int nk = radnet_cdiv(g.K, BK);
   // TileChoice.splits = number of equal work chunks the iteration space is cut into (0/1 = one workgroup per tile)
   auto launch = [&](const TileChoice& t) -> int {
     radnet_unit_table* tb = nullptr;
     g.units = nullptr;
     g.partial = nullptr;
+    g.counters = nullptr;
     if (t.splits > 1 || t.splits < 0) {
       tb = get_unit_table(ctx, g.M, g.N, g.K, t.bm, t.bn, t.splits);
       if (!tb) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv: cannot build the work-unit table");
       if ((uint64_t)tb->n_slots * t.bm * t.bn * sizeof(float) > ctx->ws_bytes) return RADNET_ERR_UNSUPPORTED;   // candidate skipped
-      if (tb->n_fix > 0 || t.splits < 0) {          // an un-split, un-swizzled table is just the plain launch
+      if (tb->n_split_tiles > 0 || t.splits < 0) {  // an un-split, un-swizzled table is just the plain launch
         g.units = tb->d_units;
         g.partial = (float*)ctx->ws;
+        g.counters = tb->d_counters;
       } else {
         tb = nullptr;
       }
@@ -659,10 +734,6 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       launch_igemm<1, false>(ctx->stream, g, t, n_units);
     }
     RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
-    if (tb && tb->n_fix > 0) {
-      hipLaunchKernelGGL(splitk_fixup_kernel, dim3(tb->n_fix), dim3(256), 0, ctx->stream, g, (const int*)tb->d_fix, t.bm, t.bn);
-      RADNET_CHECK_LAUNCH(ctx, "splitk_fixup");
-    }
     return RADNET_OK;
   };
   // tile / split-K choice: measured once per problem shape when autotuning is on, else the cost model
@@ -709,6 +780,15 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
 }
 
 }  // namespace
+
+#ifdef RADNET_DIAG_STAMPS
+// diagnostic library only (not in include/radnet_hip.h): device buffer of 8 x u64 per workgroup of the next launches
+extern "C" int radnet_diag_set_stamps(radnet_ctx* ctx, unsigned long long* dev_buf) {
+  if (!ctx) return RADNET_ERR_ARG;
+  ctx->diag_stamps = dev_buf;
+  return RADNET_OK;
+}
+#endif
 
 extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   if (!ctx || !d) return RADNET_ERR_ARG;

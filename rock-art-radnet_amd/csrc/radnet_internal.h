@@ -36,8 +36,8 @@ struct radnet_tuned {
 // Device-resident work-unit / fix-up tables of a K-split GEMM launch (conv_mfma.hip: get_unit_table).
 struct radnet_unit_table {
   int* d_units = nullptr;
-  int* d_fix = nullptr;
-  int n_units = 0, n_fix = 0, n_slots = 0;
+  unsigned* d_counters = nullptr;      // one arrival counter per K-split output tile; zero between launches
+  int n_units = 0, n_split_tiles = 0, n_slots = 0;
 };
 
 struct radnet_ctx {
@@ -63,6 +63,8 @@ struct radnet_ctx {
   double pend_flops[kMaxPending];
   int n_pending = 0;
   int n_events_alloc = 0;
+  // written only by the diagnostic build (make diag, -DRADNET_DIAG_STAMPS): per-workgroup s_memtime stamps
+  unsigned long long* diag_stamps = nullptr;
 };
 
 #define RADNET_FAIL(ctx, code, ...)                         \
