@@ -30,6 +30,10 @@ namespace {
 
 constexpr int BK = 32;          // reduction depth per LDS tile
 constexpr int NTHREADS = 256;
+#ifndef RADNET_CHAINS
+#define RADNET_CHAINS 2
+#endif
+constexpr int kChainsSmallTile = RADNET_CHAINS;   // K-interleaved accumulator sets of the 64x64 / 128x64 / 64x128 tiles
 
 struct GemmArgs {
   const float* x;        // gathered activation tensor (NHWC)
@@ -96,6 +100,8 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
 }
 
+__device__ __forceinline__ float f4_comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
 // ---- operand staging -----------------------------------------------------------------------------
 // transposed store: thread holds 4 consecutive-k values of one row; LDS layout [k][pitch] with
 // pitch == 1 (mod 32).  For a 32-lane half, rows t/8 (4 values) x kc=t%8 (8 values) hit bank
@@ -108,33 +114,53 @@ __device__ __forceinline__ void store_trans(float* s, int pitch, int row, int kc
   p[3 * pitch] = v.w;
 }
 
-// One 32-deep K tile: 16 MFMA steps of depth 2.  Operand fragments are double-buffered in registers so the
-// ds_reads of step s+1 are in flight while the MFMAs of step s issue (one wave per SIMD has nobody else to
-// hide the LDS latency behind).
-template <int TM, int TN>
+// One 32-deep K tile: 16 MFMA steps of depth 2, operand fragments prefetched from LDS into a register ring (one
+// wave per SIMD has nobody else to hide the LDS latency behind).
+// `staging(s)` is the caller's slice of operand staging for step s -- a global load of tile t+2 with its address
+// arithmetic, or an LDS store of tile t+1 -- written HERE, between the MFMA steps, because that is where it has to
+// execute: an MFMA occupies the matrix pipe for 64 cycles after it issues and the wave can issue independent VALU /
+// memory instructions meanwhile.  With all loads in front of the first MFMA and all stores behind the last one
+// (which is also where hipcc's scheduler moves them when it is free to), a lone wave per SIMD ran a 64x64 tile in
+// 2070 cycles instead of 1024 (tools/stamp_probe.py).  sched_barrier(0) after every step keeps the slices in place.
+struct NoStaging {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+//
+// Dependent MFMAs: with one 32x32 accumulator per wave (64x64 tile) every MFMA waits for the previous one to
+// retire, and a lone wave per SIMD ran at ~120 cycles per MFMA instead of 64.  CH > 1 keeps CH accumulator sets,
+// step s adding into set s % CH (the caller sums the sets after the K loop), so CH*TM*TN MFMAs are independent.
+// Fragments are fetched TWO steps ahead (3-slot register ring): an LDS read takes about as long as one MFMA.
+template <int TM, int TN, int CH, typename Staging>
 __device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int pitchA, int pitchB, int a_off, int b_off,
-                                          f32x16 (&acc)[TM][TN]) {
-  float a[2][TM], b[2][TN];
+                                          f32x16 (&acc)[CH][TM][TN], Staging staging) {
+  constexpr int kSteps = BK / 2;
+  float a[3][TM], b[3][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a[0][i] = sA[a_off + i * 32];
+  for (int p = 0; p < 2; ++p) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b[0][j] = sB[b_off + j * 32];
+    for (int i = 0; i < TM; ++i) a[p][i] = sA[2 * p * pitchA + a_off + i * 32];
 #pragma unroll
-  for (int s = 0; s < BK / 2; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < BK / 2) {
+    for (int j = 0; j < TN; ++j) b[p][j] = sB[2 * p * pitchB + b_off + j * 32];
+  }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[nxt][i] = sA[(2 * s + 2) * pitchA + a_off + i * 32];
+  for (int s = 0; s < kSteps; ++s) {
+    const int cur = s % 3, nxt = (s + 2) % 3;
+    if (s + 2 < kSteps) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[nxt][j] = sB[(2 * s + 2) * pitchB + b_off + j * 32];
+      for (int i = 0; i < TM; ++i) a[nxt][i] = sA[(2 * s + 4) * pitchA + a_off + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[nxt][j] = sB[(2 * s + 4) * pitchB + b_off + j * 32];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-    // pin the order hipcc would otherwise undo: next step's LDS reads first, then this step's MFMAs
+      for (int j = 0; j < TN; ++j)
+        acc[s % CH][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[s % CH][i][j], 0, 0, 0);
+    staging(s);
+    // order inside the step: next step's LDS reads, this step's MFMAs, then the staging slice in their shadow
     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -200,20 +226,23 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   const int kt_begin = g.units != nullptr ? unit_kb : 0;
   const int kt_end = g.units != nullptr ? unit_ke : nk_total;
 
-  // running position of the current K tile: (pos, ci0) with k0 = pos*C + ci0
-  int pos = 0, ci0 = 0;
+  // running position of the current K tile: kernel position pos = (kh, kw) and first channel ci0, k0 = pos*C + ci0
+  int pos = 0, ci0 = 0, kh_run = 0, kw_run = 0;
   if (!SMALLC) {
     int k0 = kt_begin * BK;
     pos = k0 / g.C;
     ci0 = k0 - pos * g.C;
+    kh_run = pos / g.KW;
+    kw_run = pos - kh_run * g.KW;
   }
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w, g.w_bytes);
+  const bool has_in_scale = g.in_scale != nullptr;
+  const __amdgpu_buffer_rsrc_t rscale = make_rsrc(g.in_scale, has_in_scale ? (unsigned)g.C * 4u : 0u);
   // Two register stages: the loads of tile t+2 are issued while tile t is being multiplied and tile t+1 waits in the
   // other stage, so a memory round trip (1-2 us when the line comes from the Infinity Cache or HBM) has TWO tile
-  // times to complete.  With one stage the short-K layers (8 K tiles per workgroup, 2-3 waves per SIMD) were bound
-  // by that latency, not by the matrix cores.
+  // times to complete.
   struct Stage {
     float4 a[A_ITERS], b[B_ITERS], s;
   };
@@ -221,108 +250,146 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   st0.s = make_float4(1, 1, 1, 1);
   st1.s = make_float4(1, 1, 1, 1);
 
-  auto load_tile = [&](int kt, Stage& st) {
-    // ---------------- A: implicit im2col gather (branch-free: invalid taps load from kOOB -> 0)
+  // Operand staging, cut into single operations so that mfma_tile can deal them out between the MFMA steps.
+  // Entirely branch-free (a tile past the end of this workgroup's K range, live == false, loads from kOOB -> 0, and
+  // its LDS store writes zeros into the buffer nobody reads again): the K loop body is ONE basic block.
+  constexpr int kLoadOps = A_ITERS + B_ITERS;                                   // one 16-byte buffer load each
+  constexpr int kStoreOpsA = 2 * A_ITERS;                                       // (component, chunk pair): 2 ds_write_b32
+  constexpr int kStoreOps = kStoreOpsA + (BMODE == 0 ? B_ITERS : 2 * B_ITERS);  // B: one ds_write_b128 / a b32 pair
+  // state of the tile being loaded (tile_begin -> load_op)
+  int t_kt = 0, t_ci = 0, t_kh = 0, t_kw = 0, t_fpos = 0;
+  bool t_live = false, t_kv = false;
+
+  auto tile_begin = [&](int kt, bool live, Stage& st) {
+    t_kt = kt;
+    t_live = live;
     if (SMALLC) {
       const int p = kt * 8 + a_kc;           // kernel position of this thread's chunk
-      const int kh = p / g.KW, kw = p - kh * g.KW;
-      const bool pv = p < g.npos;
-#pragma unroll
-      for (int i = 0; i < A_ITERS; ++i) {
-        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-        const bool ok = pv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-        st.a[i] = buf_load4(rx, ok ? (unsigned)(a_pix[i] + ih * g.W + iw) * 16u : kOOB);
-      }
+      t_kh = p / g.KW;
+      t_kw = p - t_kh * g.KW;
+      t_kv = live & (p < g.npos);
     } else {
-      const int kh = pos / g.KW, kw = pos - kh * g.KW;
-      const int ci = ci0 + a_kc * 4;
-      const bool kv = (pos * g.C + ci) < g.K;
-      if (g.in_scale != nullptr) {
-        st.s = make_float4(0, 0, 0, 0);
-        if (kv) st.s = *reinterpret_cast<const float4*>(g.in_scale + ci);
-      }
-#pragma unroll
-      for (int i = 0; i < A_ITERS; ++i) {
-        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-        const bool ok = kv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-        st.a[i] = buf_load4(rx, ok ? ((unsigned)(a_pix[i] + ih * g.W + iw) * (unsigned)g.C + (unsigned)ci) * 4u : kOOB);
-      }
-    }
-    // ---------------- B
-    if (BMODE == 0) {
-      constexpr int CPR = BN / 4;            // float4 chunks per k row
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) {
-        const int c = tid + NTHREADS * i;
-        const int kr = c / CPR, n4 = c - kr * CPR;
-        const int k = kt * BK + kr, n = n0 + n4 * 4;
-        const bool ok = (k < g.K) & (n < g.N);  // N is a multiple of 4 (launcher checks)
-        st.b[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
-      }
-    } else {
-      const int fpos = g.flip ? (g.npos - 1 - pos) : pos;
-      const int co = ci0 + a_kc * 4;        // gathered channel == forward output channel
-      const bool kv = (pos * g.C + co) < g.K;
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) {
-        const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
-        const bool ok = kv & (n < g.N);
-        st.b[i] = buf_load4(rw, ok ? (((unsigned)fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)co) * 4u : kOOB);
-      }
-    }
-    if (!SMALLC) {
+      t_ci = ci0 + a_kc * 4;                 // gathered channel (dgrad: == forward output channel)
+      t_kv = live & ((pos * g.C + t_ci) < g.K);
+      t_kh = kh_run;
+      t_kw = kw_run;
+      t_fpos = g.flip ? (g.npos - 1 - pos) : pos;
+      // raw value; consumed (and replaced by 1 when there is no in_scale: empty descriptor, reads 0) only at the LDS
+      // store one tile later -- touching it here would make the wave wait for the load it has just issued
+      st.s = buf_load4(rscale, t_kv ? (unsigned)t_ci * 4u : kOOB);
+      // advance the running position to the following tile
       ci0 += BK;
-      if (ci0 >= g.C) { ci0 = 0; ++pos; }
+      const bool wrap = ci0 >= g.C;
+      ci0 = wrap ? 0 : ci0;
+      pos += wrap ? 1 : 0;
+      kw_run += wrap ? 1 : 0;
+      const bool wrap_w = kw_run >= g.KW;
+      kw_run = wrap_w ? 0 : kw_run;
+      kh_run += wrap_w ? 1 : 0;
     }
   };
 
-  auto store_tile = [&](int buf, const Stage& st) {
+  auto load_op = [&](int idx, Stage& st) {
+    if (idx < A_ITERS) {
+      // ---------------- A: implicit im2col gather (invalid taps load from kOOB -> 0)
+      const int i = idx;
+      const int ih = a_ih0[i] + t_kh, iw = a_iw0[i] + t_kw;
+      const bool ok = t_kv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+      const unsigned pix = (unsigned)(a_pix[i] + ih * g.W + iw);
+      st.a[i] = buf_load4(rx, ok ? (SMALLC ? pix * 16u : (pix * (unsigned)g.C + (unsigned)t_ci) * 4u) : kOOB);
+    } else if (BMODE == 0) {
+      constexpr int CPR = BN / 4;            // float4 chunks per k row
+      const int i = idx - A_ITERS;
+      const int c = tid + NTHREADS * i;
+      const int kr = c / CPR, n4 = c - kr * CPR;
+      const int k = t_kt * BK + kr, n = n0 + n4 * 4;
+      const bool ok = t_live & (k < g.K) & (n < g.N);  // N is a multiple of 4 (launcher checks)
+      st.b[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
+    } else {
+      const int i = idx - A_ITERS;
+      const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
+      const bool ok = t_kv & (n < g.N);
+      st.b[i] = buf_load4(rw, ok ? (((unsigned)t_fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)t_ci) * 4u : kOOB);
+    }
+  };
+
+  // transposed stores (A always, B for dgrad): thread holds 4 consecutive-k values of one row, LDS layout [k][pitch]
+  // with pitch == 1 (mod 32) -> rows t/8 x chunks t%8 of a half-wave hit 32 distinct banks.  One op = one k
+  // component of two row chunks (the compiler pairs them into a ds_write2_b32).
+  auto store_op = [&](int op, int buf, const Stage& st) {
     float* sA = sA0 + buf * BK * PA;
     float* sB = sB0 + buf * BK * PB;
+    if (op < kStoreOpsA) {
+      const int c = op / (A_ITERS / 2), ip = op - c * (A_ITERS / 2);
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      float4 v = st.a[i];
-      v.x *= st.s.x; v.y *= st.s.y; v.z *= st.s.z; v.w *= st.s.w;
-      store_trans(sA, PA, (tid >> 3) + 32 * i, a_kc, v);
-    }
-    if (BMODE == 0) {
-      constexpr int CPR = BN / 4;
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) {
-        const int c = tid + NTHREADS * i;
-        const int kr = c / CPR, n4 = c - kr * CPR;
-        *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = st.b[i];
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * ip + h;
+        sA[(a_kc * 4 + c) * PA + (tid >> 3) + 32 * i] = f4_comp(st.a[i], c) * (has_in_scale ? f4_comp(st.s, c) : 1.f);
       }
+    } else if (BMODE == 0) {
+      constexpr int CPR = BN / 4;
+      const int i = op - kStoreOpsA;
+      const int cc = tid + NTHREADS * i;
+      const int kr = cc / CPR, n4 = cc - kr * CPR;
+      *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = st.b[i];
     } else {
+      const int q = op - kStoreOpsA;
+      const int c = q / (B_ITERS / 2), ip = q - c * (B_ITERS / 2);
 #pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) store_trans(sB, PB, (tid >> 3) + 32 * i, a_kc, st.b[i]);
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * ip + h;
+        sB[(a_kc * 4 + c) * PB + (tid >> 3) + 32 * i] = f4_comp(st.b[i], c);
+      }
     }
   };
 
-  f32x16 acc[TM][TN];
+  // independent 32x32 accumulators per wave (see mfma_tile): two K-interleaved sets for the tiles with fewer than 4
+  constexpr int CH = (TM * TN >= 4) ? 1 : kChainsSmallTile;
+  f32x16 accs[CH][TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int c = 0; c < CH; ++c)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
 
   if (kt_begin < kt_end) {
-    load_tile(kt_begin, st0);
-    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, st1);
-    store_tile(0, st0);
+    tile_begin(kt_begin, true, st0);
+#pragma unroll
+    for (int op = 0; op < kLoadOps; ++op) load_op(op, st0);
+    tile_begin(kt_begin + 1, kt_begin + 1 < kt_end, st1);
+#pragma unroll
+    for (int op = 0; op < kLoadOps; ++op) load_op(op, st1);
+#pragma unroll
+    for (int op = 0; op < kStoreOps; ++op) store_op(op, 0, st0);
     __syncthreads();
 #ifdef RADNET_DIAG_STAMPS
     t_first = __builtin_amdgcn_s_memtime();
 #endif
     const int a_off = hi * PA + wm * (BM / 2) + l31;
     const int b_off = hi * PB + wn * (BN / 2) + l31;
-    // invariant at the top of step(kt, cur): LDS buffer cur holds tile kt; stage `nxt` holds tile kt+1 (in flight or
-    // landed); stage `cur` is free
+    // invariant at the top of step(kt, buf): LDS buffer `buf` holds tile kt; stage `nxt` holds tile kt+1 (in flight or
+    // landed); stage `cur` is free.  MFMA steps 0 .. kLoadOps-1 each carry one global load of tile kt+2, the steps
+    // after them (all but the last, which has no MFMA behind it to hide under) the LDS stores of tile kt+1.
+    constexpr int kSteps = BK / 2;
+    constexpr int kStoreSteps = kSteps - 1 - kLoadOps;
+    constexpr int kStoresPerStep = (kStoreOps + kStoreSteps - 1) / kStoreSteps;
+    static_assert(kStoreSteps >= 1, "tile too large for the 16-step staging schedule");
     auto step = [&](int kt, int buf, Stage& cur, Stage& nxt) {
-      if (kt + 2 < kt_end) load_tile(kt + 2, cur);
-      mfma_tile<TM, TN>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, acc);
-      if (kt + 1 < kt_end) store_tile(buf ^ 1, nxt);
+      tile_begin(kt + 2, kt + 2 < kt_end, cur);
+      mfma_tile<TM, TN, CH>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, accs, [&](int s) {
+        if (s < kLoadOps) {
+          load_op(s, cur);
+        } else if (s < kSteps - 1) {
+#pragma unroll
+          for (int q = 0; q < kStoresPerStep; ++q) {
+            const int op = (s - kLoadOps) * kStoresPerStep + q;
+            if (op < kStoreOps) store_op(op, buf ^ 1, nxt);
+          }
+        }
+      });
       __syncthreads();
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
@@ -330,6 +397,13 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       if (kt + 1 < kt_end) step(kt + 1, 1, st1, st0);
     }
   }
+  f32x16(&acc)[TM][TN] = accs[0];
+#pragma unroll
+  for (int c = 1; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += accs[c][i][j];
 #ifdef RADNET_DIAG_STAMPS
   t_loop = __builtin_amdgcn_s_memtime();
   // stamps go to a buffer of their own; nothing the kernel outputs is computed from them.  The epilogue stamp is
@@ -534,13 +608,16 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
     }
   };
 
-  f32x16 acc[TM][TN];
+  constexpr int CH = (TM * TN >= 4) ? 1 : kChainsSmallTile;     // independent accumulator sets, see mfma_tile
+  f32x16 accs[CH][TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int c = 0; c < CH; ++c)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
 
   if (mt_begin < mt_end) {
     load_tile(mt_begin);
@@ -552,11 +629,18 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
       const int buf = (mt - mt_begin) & 1;
       const bool more = mt + 1 < mt_end;
       if (more) load_tile(mt + 1);
-      mfma_tile<TM, TN>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, acc);
+      mfma_tile<TM, TN, CH>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, accs, NoStaging());
       if (more) store_tile(buf ^ 1);
       __syncthreads();
     }
   }
+  f32x16(&acc)[TM][TN] = accs[0];
+#pragma unroll
+  for (int c = 1; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += accs[c][i][j];
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
