@@ -164,6 +164,66 @@ __device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int 
   }
 }
 
+// The same tile for the forward / dgrad kernel, whose gathered operand arrives as 4 consecutive k of one row: it is
+// kept ROW-major in LDS ([row][kRowPitch], one ds_write_b128 per chunk -- the transposed ds_write_b32 stores it
+// replaces cost ~85 cycles of MFMA time each, tools/stamp_probe.py) and its fragments are read 4 k at a time with
+// ds_read_b128.  That works because the order of k inside a tile is free as long as A and B agree: MFMA step
+// s = 4q + j multiplies k = 8q + j in lanes 0-31 and k = 8q + 4 + j in lanes 32-63, so lane (row, h) reads the 16
+// bytes at k = 8q + 4h once per q and uses component j in step 4q + j; the k-major operand (forward weights, [k][n])
+// reads row 8q + 4h + j.  kRowPitch = 36 words: a ds_read_b128 lane group (16 lanes, rows {0-3,12-15,20-27} + 4g)
+// lands on 16 distinct 4-bank sets, and the 8-lane groups of the ds_write_b128 cover 32 consecutive words.
+constexpr int kRowPitch = BK + 4;
+template <int TM, int TN, int CH, bool B_ROWMAJOR, typename Staging>
+__device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB, int pitchB, int a_off, int b_off,
+                                               f32x16 (&acc)[CH][TM][TN], Staging staging) {
+  constexpr int kSteps = BK / 2;
+  float4 af[2][TM], bq[2][TN];
+  float bf[3][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(sA + a_off + i * 32 * kRowPitch);
+  if (B_ROWMAJOR) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bq[0][j] = *reinterpret_cast<const float4*>(sB + b_off + j * 32 * kRowPitch);
+  } else {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[p][j] = sB[p * pitchB + b_off + j * 32];
+  }
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) {
+    const int q = s >> 2, c = s & 3;
+    const bool group_reads = c == 1 && q + 1 < 4;     // next group's 16-byte fragments, three steps ahead of their first use
+    const bool step_reads = !B_ROWMAJOR && s + 2 < kSteps;
+    if (group_reads) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = *reinterpret_cast<const float4*>(sA + a_off + i * 32 * kRowPitch + 8 * (q + 1));
+      if (B_ROWMAJOR) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bq[(q + 1) & 1][j] = *reinterpret_cast<const float4*>(sB + b_off + j * 32 * kRowPitch + 8 * (q + 1));
+      }
+    }
+    if (step_reads) {
+      const int s2 = s + 2;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[s2 % 3][j] = sB[(8 * (s2 >> 2) + (s2 & 3)) * pitchB + b_off + j * 32];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[s % CH][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_comp(af[q & 1][i], c), B_ROWMAJOR ? f4_comp(bq[q & 1][j], c) : bf[s % 3][j],
+                                                                 acc[s % CH][i][j], 0, 0, 0);
+    staging(s);
+    // order inside the step: the LDS reads issued here, this step's MFMAs, then the staging slice in their shadow
+    if (group_reads && (B_ROWMAJOR || step_reads)) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    else if (group_reads) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+    else if (step_reads) __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- forward / dgrad kernel -------------------------------------------------------------------------
 // BMODE 0: B is [K][ldw] row-major (forward).  BMODE 1: B element (k=(pos,co), n=ci) lives at
 //          w[((flip(pos)*cin_fwd + ci) * ldw) + co]  (dgrad: same weight buffer, read transposed).
@@ -171,13 +231,15 @@ __device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int 
 template <int BM, int BN, int BMODE, bool SMALLC>
 __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave in each direction
-  constexpr int PA = BM + 1;                    // A pitch (transposed store)
-  constexpr int PB = (BMODE == 0) ? (BN + 4) : (BN + 1);
+  constexpr int PB = BN + 4;                    // forward weights: k-major [BK][PB]
   constexpr int A_ITERS = BM / 32;              // float4 chunks per thread (A)
   constexpr int B_ITERS = BN / 32;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (PA + PB)];
+  // one LDS buffer: A row-major [BM][kRowPitch]; B k-major [BK][PB] (forward) or row-major [BN][kRowPitch] (dgrad)
+  constexpr int kBufA = BM * kRowPitch;
+  constexpr int kBufB = (BMODE == 0) ? BK * PB : BN * kRowPitch;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (kBufA + kBufB)];
   float* sA0 = lds;
-  float* sB0 = lds + 2 * BK * PA;
+  float* sB0 = lds + 2 * kBufA;
 
   RADNET_STAMP(t_start);
 #ifdef RADNET_DIAG_STAMPS
@@ -203,22 +265,36 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 
   // ---- per-thread A rows: decode m -> (image, oh, ow) once
   const int a_kc = tid & 7;
-  int a_pix[A_ITERS], a_ih0[A_ITERS], a_iw0[A_ITERS];
+  // a_base = byte offset of (image, ih0, iw0, channel 0), possibly negative (halo); a tap (kh, kw, ci) then adds one
+  // per-tile offset, and only the two range compares remain per load (no multiplies in the K loop: v_mul_lo_u32
+  // is a 16-cycle instruction).  Rows past M get ih0 far below zero, which fails the range compare of every tap.
+  int a_base[A_ITERS], a_ih0[A_ITERS], a_iw0[A_ITERS];
+  const int a_cbytes = (SMALLC ? 4 : g.C) * 4;
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
-    int m = m0 + (tid >> 3) + 32 * i;
-    if (m < g.M) {
-      int img = div_magic(m, g.magic_ohow);
-      int rem = m - img * g.OHOW;
-      int oh = div_magic(rem, g.magic_ow);
-      int ow = rem - oh * g.OW;
-      a_pix[i] = img * g.H * g.W;
-      a_ih0[i] = oh * g.stride - g.pad_t;
-      a_iw0[i] = ow * g.stride - g.pad_l;
-    } else {
-      a_pix[i] = -1;
-      a_ih0[i] = 0;
-      a_iw0[i] = 0;
+    const int m = m0 + (tid >> 3) + 32 * i;
+    const int mc = m < g.M ? m : 0;
+    const int img = div_magic(mc, g.magic_ohow);
+    const int rem = mc - img * g.OHOW;
+    const int oh = div_magic(rem, g.magic_ow);
+    const int ow = rem - oh * g.OW;
+    a_ih0[i] = m < g.M ? oh * g.stride - g.pad_t : -(1 << 24);
+    a_iw0[i] = ow * g.stride - g.pad_l;
+    a_base[i] = ((img * g.H + (oh * g.stride - g.pad_t)) * g.W + a_iw0[i]) * a_cbytes;
+  }
+
+  // forward weights: byte offset of this thread's chunk (row kr, column n) in K tile 0; a tile adds BK rows
+  int b_base[B_ITERS];
+  bool b_nvalid[B_ITERS];
+  const int b_tile_bytes = BK * g.ldw * 4;
+  if (BMODE == 0) {
+    constexpr int CPR = BN / 4;
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int c = tid + NTHREADS * i;
+      const int kr = c / CPR, n = n0 + (c - kr * CPR) * 4;
+      b_base[i] = (kr * g.ldw + n) * 4;
+      b_nvalid[i] = n < g.N;
     }
   }
 
@@ -254,10 +330,9 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   // Entirely branch-free (a tile past the end of this workgroup's K range, live == false, loads from kOOB -> 0, and
   // its LDS store writes zeros into the buffer nobody reads again): the K loop body is ONE basic block.
   constexpr int kLoadOps = A_ITERS + B_ITERS;                                   // one 16-byte buffer load each
-  constexpr int kStoreOpsA = 2 * A_ITERS;                                       // (component, chunk pair): 2 ds_write_b32
-  constexpr int kStoreOps = kStoreOpsA + (BMODE == 0 ? B_ITERS : 2 * B_ITERS);  // B: one ds_write_b128 / a b32 pair
+  constexpr int kStoreOps = A_ITERS + B_ITERS;                                  // one ds_write_b128 each
   // state of the tile being loaded (tile_begin -> load_op)
-  int t_kt = 0, t_ci = 0, t_kh = 0, t_kw = 0, t_fpos = 0;
+  int t_kt = 0, t_ci = 0, t_kh = 0, t_kw = 0, t_fpos = 0, t_aoff = 0;
   bool t_live = false, t_kv = false;
 
   auto tile_begin = [&](int kt, bool live, Stage& st) {
@@ -268,15 +343,17 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       t_kh = p / g.KW;
       t_kw = p - t_kh * g.KW;
       t_kv = live & (p < g.npos);
+      t_aoff = (t_kh * g.W + t_kw) * 16;
     } else {
       t_ci = ci0 + a_kc * 4;                 // gathered channel (dgrad: == forward output channel)
       t_kv = live & ((pos * g.C + t_ci) < g.K);
       t_kh = kh_run;
       t_kw = kw_run;
       t_fpos = g.flip ? (g.npos - 1 - pos) : pos;
+      t_aoff = ((kh_run * g.W + kw_run) * g.C + t_ci) * 4;   // scalar multiplies + one vector add
       // raw value; consumed (and replaced by 1 when there is no in_scale: empty descriptor, reads 0) only at the LDS
       // store one tile later -- touching it here would make the wave wait for the load it has just issued
-      st.s = buf_load4(rscale, t_kv ? (unsigned)t_ci * 4u : kOOB);
+      if (BMODE == 1) st.s = buf_load4(rscale, t_kv ? (unsigned)t_ci * 4u : kOOB);   // forward never scales its input
       // advance the running position to the following tile
       ci0 += BK;
       const bool wrap = ci0 >= g.C;
@@ -294,17 +371,15 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
       // ---------------- A: implicit im2col gather (invalid taps load from kOOB -> 0)
       const int i = idx;
       const int ih = a_ih0[i] + t_kh, iw = a_iw0[i] + t_kw;
-      const bool ok = t_kv & (a_pix[i] >= 0) & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-      const unsigned pix = (unsigned)(a_pix[i] + ih * g.W + iw);
-      st.a[i] = buf_load4(rx, ok ? (SMALLC ? pix * 16u : (pix * (unsigned)g.C + (unsigned)t_ci) * 4u) : kOOB);
+      const bool ok = t_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+      st.a[i] = buf_load4(rx, ok ? (unsigned)(a_base[i] + t_aoff) : kOOB);
     } else if (BMODE == 0) {
       constexpr int CPR = BN / 4;            // float4 chunks per k row
       const int i = idx - A_ITERS;
       const int c = tid + NTHREADS * i;
-      const int kr = c / CPR, n4 = c - kr * CPR;
-      const int k = t_kt * BK + kr, n = n0 + n4 * 4;
-      const bool ok = t_live & (k < g.K) & (n < g.N);  // N is a multiple of 4 (launcher checks)
-      st.b[i] = buf_load4(rw, ok ? ((unsigned)k * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB);
+      const int kr = c / CPR;
+      const bool ok = t_live & (t_kt * BK + kr < g.K) & b_nvalid[i];   // N is a multiple of 4 (launcher checks)
+      st.b[i] = buf_load4(rw, ok ? (unsigned)(b_base[i] + t_kt * b_tile_bytes) : kOOB);
     } else {
       const int i = idx - A_ITERS;
       const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
@@ -313,33 +388,30 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     }
   };
 
-  // transposed stores (A always, B for dgrad): thread holds 4 consecutive-k values of one row, LDS layout [k][pitch]
-  // with pitch == 1 (mod 32) -> rows t/8 x chunks t%8 of a half-wave hit 32 distinct banks.  One op = one k
-  // component of two row chunks (the compiler pairs them into a ds_write2_b32).
+  // LDS stores: every operation is one ds_write_b128 of the 4 consecutive k (A, dgrad B) or n (forward B) a thread
+  // loaded; the gathered operand is scaled on the way (dgrad: frozen-BN factor of the channel).
   auto store_op = [&](int op, int buf, const Stage& st) {
-    float* sA = sA0 + buf * BK * PA;
-    float* sB = sB0 + buf * BK * PB;
-    if (op < kStoreOpsA) {
-      const int c = op / (A_ITERS / 2), ip = op - c * (A_ITERS / 2);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * ip + h;
-        sA[(a_kc * 4 + c) * PA + (tid >> 3) + 32 * i] = f4_comp(st.a[i], c) * (has_in_scale ? f4_comp(st.s, c) : 1.f);
+    float* sA = sA0 + buf * kBufA;
+    float* sB = sB0 + buf * kBufB;
+    if (op < A_ITERS) {
+      const int i = op;
+      float4 v = st.a[i];
+      if (BMODE == 1) {                     // select, not a branch: the K loop stays one basic block
+        v.x *= has_in_scale ? st.s.x : 1.f;
+        v.y *= has_in_scale ? st.s.y : 1.f;
+        v.z *= has_in_scale ? st.s.z : 1.f;
+        v.w *= has_in_scale ? st.s.w : 1.f;
       }
+      *reinterpret_cast<float4*>(sA + ((tid >> 3) + 32 * i) * kRowPitch + a_kc * 4) = v;
     } else if (BMODE == 0) {
       constexpr int CPR = BN / 4;
-      const int i = op - kStoreOpsA;
+      const int i = op - A_ITERS;
       const int cc = tid + NTHREADS * i;
       const int kr = cc / CPR, n4 = cc - kr * CPR;
       *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = st.b[i];
     } else {
-      const int q = op - kStoreOpsA;
-      const int c = q / (B_ITERS / 2), ip = q - c * (B_ITERS / 2);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * ip + h;
-        sB[(a_kc * 4 + c) * PB + (tid >> 3) + 32 * i] = f4_comp(st.b[i], c);
-      }
+      const int i = op - A_ITERS;
+      *reinterpret_cast<float4*>(sB + ((tid >> 3) + 32 * i) * kRowPitch + a_kc * 4) = st.b[i];
     }
   };
 
@@ -368,8 +440,9 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 #ifdef RADNET_DIAG_STAMPS
     t_first = __builtin_amdgcn_s_memtime();
 #endif
-    const int a_off = hi * PA + wm * (BM / 2) + l31;
-    const int b_off = hi * PB + wn * (BN / 2) + l31;
+    // fragment offsets (see mfma_tile_rows): row-major operands start at (row, k = 4*hi), the k-major one at row 4*hi
+    const int a_off = (wm * (BM / 2) + l31) * kRowPitch + 4 * hi;
+    const int b_off = (BMODE == 0) ? 4 * hi * PB + wn * (BN / 2) + l31 : (wn * (BN / 2) + l31) * kRowPitch + 4 * hi;
     // invariant at the top of step(kt, buf): LDS buffer `buf` holds tile kt; stage `nxt` holds tile kt+1 (in flight or
     // landed); stage `cur` is free.  MFMA steps 0 .. kLoadOps-1 each carry one global load of tile kt+2, the steps
     // after them (all but the last, which has no MFMA behind it to hide under) the LDS stores of tile kt+1.
@@ -379,18 +452,24 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     static_assert(kStoreSteps >= 1, "tile too large for the 16-step staging schedule");
     auto step = [&](int kt, int buf, Stage& cur, Stage& nxt) {
       tile_begin(kt + 2, kt + 2 < kt_end, cur);
-      mfma_tile<TM, TN, CH>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, accs, [&](int s) {
+      mfma_tile_rows<TM, TN, CH, BMODE != 0>(sA0 + buf * kBufA, sB0 + buf * kBufB, PB, a_off, b_off, accs, [&](int s) {
         if (s < kLoadOps) {
+#ifndef RADNET_DIAG_SKIP_LOADS
           load_op(s, cur);
+#endif
         } else if (s < kSteps - 1) {
+#ifndef RADNET_DIAG_SKIP_STORES
 #pragma unroll
           for (int q = 0; q < kStoresPerStep; ++q) {
             const int op = (s - kLoadOps) * kStoresPerStep + q;
             if (op < kStoreOps) store_op(op, buf ^ 1, nxt);
           }
+#endif
         }
       });
+#ifndef RADNET_DIAG_SKIP_BARRIER
       __syncthreads();
+#endif
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
       step(kt, 0, st0, st1);
@@ -791,6 +870,9 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.mask_bytes = g.mask ? (unsigned)(((uint64_t)(g.M - 1) * g.ld_mask + g.N) * 4ull) : 0u;
   }
   g.stamps = ctx->diag_stamps;
+#ifdef RADNET_DIAG_STAMPS
+  if (getenv("RADNET_DIAG_NOMEM")) g.x_bytes = g.w_bytes = 0;   // every operand load out of range: returns 0 without touching memory
+#endif
   const int nk = radnet_cdiv(g.K, BK);
   // TileChoice.splits = number of equal work chunks the iteration space is cut into (0/1 = one workgroup per tile)
   auto launch = [&](const TileChoice& t) -> int {

@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ in, float
   f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
   float a = in[tid], b = in[tid + 256];
   unsigned junk = tid;
+  float fx[4] = {a, b, a + 1.f, b + 1.f};
   float4 ld[8] = {};
   const float* sA = lds + (lane >> 5) * 65 + (lane & 31);
   const float* sB = lds + 32 * 65 + (lane >> 5) * 68 + (lane & 31);
@@ -90,6 +91,56 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ in, float
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
+    } else if (VARIANT >= 100 && VARIANT < 200) {
+      // conv loop shape plus (VARIANT - 100) independent v_fma_f32 per MFMA step (4 separate dependency chains)
+      float fa[3], fb[3];
+      fa[0] = sA[0]; fb[0] = sB[0]; fa[1] = sA[2 * 65]; fb[1] = sB[2 * 68];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + 2 < 16) {
+          fa[(s + 2) % 3] = sA[(2 * s + 4) * 65];
+          fb[(s + 2) % 3] = sB[(2 * s + 4) * 68];
+        }
+        if ((s & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % 3], fb[s % 3], acc0, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % 3], fb[s % 3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < VARIANT - 100; ++v) fx[v & 3] = __builtin_fmaf(fx[v & 3], a, b);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    } else if (VARIANT >= 50 && VARIANT < 80) {
+      // the conv K loop's shape: one chain pair, fragments prefetched two steps ahead, barrier per tile, and per tile
+      //   50+W: W LDS stores (ds_write_b32 pairs, transposed-store pattern) from registers, one per step from step 4
+      //   60+W: the same with ds_write_b128
+      //   70+L: L 16-byte buffer-style global loads (results only summed after the loop), one per step from step 0
+      float fa[3], fb[3];
+      fa[0] = sA[0]; fb[0] = sB[0]; fa[1] = sA[2 * 65]; fb[1] = sB[2 * 68];
+      float* wbase = lds + 32 * 133 + (t & 1) * 0 + (tid >> 3) + (tid & 7) * 4 * 65;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + 2 < 16) {
+          fa[(s + 2) % 3] = sA[(2 * s + 4) * 65];
+          fb[(s + 2) % 3] = sB[(2 * s + 4) * 68];
+        }
+        if ((s & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % 3], fb[s % 3], acc0, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % 3], fb[s % 3], acc1, 0, 0, 0);
+        if (VARIANT >= 50 && VARIANT < 60 && s >= 4 && s < 4 + (VARIANT - 50)) {
+          wbase[(s & 3) * 65] = a;
+          wbase[(s & 3) * 65 + 32] = b;
+        }
+        if (VARIANT >= 60 && VARIANT < 70 && s >= 4 && s < 4 + (VARIANT - 60))
+          reinterpret_cast<float4*>(lds + 32 * 133)[tid + 256 * (s & 3)] = make_float4(a, b, a, b);
+        if (VARIANT >= 70 && s < VARIANT - 70) {
+          const float4 nv = reinterpret_cast<const float4*>(in)[(tid + 256 * s + 64 * t) & 1023];
+          ld[s].x += nv.x;
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
     } else if (VARIANT >= 40 && VARIANT < 50) {
       // same with (VARIANT - 40) 16-byte global loads per tile issued after the first MFMAs, consumed next tile,
       // and as many ds_write_b128 of the previous tile's values into the other half of the LDS array
@@ -109,11 +160,12 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ in, float
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  (void)0;
   f32x16 r = acc0 + acc1 + acc2 + acc3;
   float sum = 0.f;
   for (int i = 0; i < 16; ++i) sum += r[i];
   for (int i = 0; i < 8; ++i) sum += ld[i].x;
-  out[blockIdx.x * 256 + tid] = sum + (float)junk;
+  out[blockIdx.x * 256 + tid] = sum + (float)junk + fx[0] + fx[1] + fx[2] + fx[3];
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -152,6 +204,20 @@ int main() {
     run<22>("LDS, 2 chains, barrier, +12 VALU per MFMA", w, in, out, cyc);
     run<26>("LDS, 2 chains, barrier, +16 VALU per MFMA", w, in, out, cyc);
     run<34>("LDS, 2 chains, barrier, +24 VALU per MFMA", w, in, out, cyc);
+    run<50>("conv loop shape, no staging", w, in, out, cyc);
+    run<104>("conv loop shape, +4 v_fma_f32 per MFMA", w, in, out, cyc);
+    run<108>("conv loop shape, +8 v_fma_f32 per MFMA", w, in, out, cyc);
+    run<112>("conv loop shape, +12 v_fma_f32 per MFMA", w, in, out, cyc);
+    run<116>("conv loop shape, +16 v_fma_f32 per MFMA", w, in, out, cyc);
+    run<124>("conv loop shape, +24 v_fma_f32 per MFMA", w, in, out, cyc);
+    run<52>("conv loop shape, 2 ds_write2_b32 per tile", w, in, out, cyc);
+    run<54>("conv loop shape, 4 ds_write2_b32 per tile", w, in, out, cyc);
+    run<58>("conv loop shape, 8 ds_write2_b32 per tile", w, in, out, cyc);
+    run<62>("conv loop shape, 2 ds_write_b128 per tile", w, in, out, cyc);
+    run<64>("conv loop shape, 4 ds_write_b128 per tile", w, in, out, cyc);
+    run<72>("conv loop shape, 2 global_load_dwordx4 per tile", w, in, out, cyc);
+    run<74>("conv loop shape, 4 global_load_dwordx4 per tile", w, in, out, cyc);
+    run<78>("conv loop shape, 8 global_load_dwordx4 per tile", w, in, out, cyc);
     run<42>("LDS, 2 chains, barrier, 2 global loads + 2 ds_write_b128 per tile", w, in, out, cyc);
     run<44>("LDS, 2 chains, barrier, 4 global loads + 4 ds_write_b128 per tile", w, in, out, cyc);
     run<48>("LDS, 2 chains, barrier, 8 global loads + 8 ds_write_b128 per tile", w, in, out, cyc);

@@ -18,7 +18,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
 
 from radnet_hip import lib as L  # noqa: E402
 
-L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libradnet_hip_diag.so")
+L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ.get("RADNET_DIAG_LIB", "libradnet_hip_diag.so"))
 
 # name, nb, h, w, cin, cout, k, stride, pad, residual, (tile_m, tile_n, slices)
 SHAPES = [
