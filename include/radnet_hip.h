@@ -64,7 +64,8 @@ int radnet_timing_reset(radnet_ctx* ctx);
  *   forward :  y[m][n] = act( (sum_k im2col(x)[m][k] * w[k][n]) * scale[n] + shift[n] + addend[m][n] )
  *   dgrad   :  dx[p][c] = ( sum_{kh,kw,n} (dy*gscale)[..][n] * w[(kh,kw,c)][n] + addend[p][c] ) masked
  *              by mask[p][c] > 0   (stride 1 only; ReLU backward of the producer fused as the mask)
- *   wgrad   :  dw[k][n] (+)= sum_m im2col(x)[m][k] * (dy*gscale)[m][n];  db[n] via radnet_colsum
+ *   wgrad   :  dw[k][n] (+)= sum_m im2col(x)[m][k] * (dy*gscale)[m][n];
+ *              db[n] (+)= sum_m (dy*gscale)[m][n] in the same launch when db is set (else radnet_colsum)
  */
 typedef struct radnet_conv_desc {
   const float* x;        /* forward input  [nb][h][w][c]                                   */
@@ -89,6 +90,7 @@ typedef struct radnet_conv_desc {
   float* dw;             /* wgrad output [kh*kw*c][ldw]                                    */
   int32_t ld_dy, ld_dx, ld_dx_add, ld_dx_mask;
   int32_t dw_accumulate; /* 0: overwrite dw; 1: dw += ; 2: dw was zeroed by the caller (no memset, no atomics unless split) */
+  float* db;             /* wgrad: bias gradient [n], same accumulate mode as dw, or 0                   */
 } radnet_conv_desc;
 
 int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d);
@@ -141,9 +143,11 @@ int radnet_rpn_loss(radnet_ctx* ctx, const float* pred, int32_t ld_pred, const f
 int radnet_det_loss(radnet_ctx* ctx, const float* p_cls, const float* p_regr, const float* y1, const float* y2,
                     int32_t r, int32_t nc, int32_t nreg, float* dz, float* losses);
 
-/* ---- optimizer: keras.optimizers.Adam over one flat arena (train.py:236-252) ----------------- */
-int radnet_adam_step(radnet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int32_t t, float lr,
-                     float beta1, float beta2, float eps, float grad_scale);
+/* ---- optimizer: keras.optimizers.Adam over one flat arena (train.py:236-252) -----------------
+ * zero_grad != 0: the gradient arena is cleared in the same pass (each value is read once and overwritten with 0),
+ * so the next step's backward can accumulate into it without a separate memset. */
+int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, int32_t zero_grad);
 
 /* ---- proposal decode + greedy NMS (rpn.py:68-172, 299-344, 380-455), fp64 ---------------------
  * pred: fused head output [rows*cols][ld_pred] (scores in [0,A), regression in [A,5A)).

@@ -608,6 +608,7 @@ struct WgradArgs {
   const float* dy;
   const float* gscale;
   float* dw;
+  float* db;             // bias gradient [N] (atomic adds by the workgroups of the first k tile) or null
   int H, W, C, OH, OW, KW, stride, pad_t, pad_l;
   int M, N, K;
   int ld_dy, ldw;
@@ -654,6 +655,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(g.dy, g.dy_bytes);
   float4 ra[A_ITERS], rb[B_ITERS];
+  // bias gradient: the workgroups of the first k tile see every (dy * gscale) row of their m range exactly once on
+  // its way into LDS; they keep a running column sum and add it to db at the end (keras Conv2D bias / the beta-free
+  // FixedBatchNormalization shift: d/db = sum over pixels of the scaled output gradient)
+  const bool do_bias = g.db != nullptr && blockIdx.x == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -684,6 +690,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
       float4 v = rb[i];
       v.x *= gs.x; v.y *= gs.y; v.z *= gs.z; v.w *= gs.w;
       *reinterpret_cast<float4*>(sB + (b_mr + (NTHREADS / CPRB) * i) * PB + b_n4 * 4) = v;
+      if (do_bias) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }   // rows past M / columns past N loaded as 0
     }
   };
 
@@ -720,6 +727,26 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] += accs[c][i][j];
+
+  if (do_bias) {             // uniform per workgroup; the staging array is free after the loop's last barrier
+    float4* red = reinterpret_cast<float4*>(lds);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < CPRB) {
+      float4 t = red[tid];
+      for (int q = 1; q < NTHREADS / CPRB; ++q) {
+        const float4 u = red[tid + q * CPRB];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      const int n = n0 + tid * 4;
+      if (n < g.N) {           // N is a multiple of 4
+        atomicAdd(g.db + n, t.x);
+        atomicAdd(g.db + n + 1, t.y);
+        atomicAdd(g.db + n + 2, t.z);
+        atomicAdd(g.db + n + 3, t.w);
+      }
+    }
+  }
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -997,7 +1024,7 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   if (!ctx || !d) return RADNET_ERR_ARG;
   if (!d->x || !d->dy || !d->dw) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: null tensor");
   WgradArgs g{};
-  g.x = d->x; g.dy = d->dy; g.gscale = d->gscale; g.dw = d->dw;
+  g.x = d->x; g.dy = d->dy; g.gscale = d->gscale; g.dw = d->dw; g.db = nullptr;
   g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow; g.KW = d->kw;
   g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
   g.M = d->nb * d->oh * d->ow; g.N = d->n; g.K = d->kh * d->kw * d->c;
@@ -1076,6 +1103,9 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   }
   radnet_timing_begin(ctx);
   {
+    // bias gradient in the same launch (the measurement launches above ran without it); atomics need zeros to add to
+    g.db = d->db;
+    if (d->db && d->dw_accumulate == 0) RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->db, 0, (size_t)g.N * sizeof(float), ctx->stream));
     int rc = launch(bmk, bn, splits);
     if (rc != RADNET_OK) return rc;
   }

@@ -243,11 +243,11 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
 }
 
 // ---- keras.optimizers.Adam (Keras 2 update rule) over a flat arena ------------------------------------------
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps,
-                                                   float gs) {
+                                                   float gs, int zero_grad) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
 #define ADAM1(q)                                         \
   {                                                      \
@@ -261,6 +261,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -534,15 +535,15 @@ extern "C" int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t
   return RADNET_OK;
 }
 
-extern "C" int radnet_adam_step(radnet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
-                                float beta2, float eps, float grad_scale) {
+extern "C" int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
+                                float beta2, float eps, float grad_scale, int32_t zero_grad) {
   if (!ctx || !p || !g || !m || !v) return RADNET_ERR_ARG;
   if (n % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: arena length must be a multiple of 4");
   if (t < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: step counter starts at 1");
   // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (keras.optimizers.Adam.get_updates)
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
-                     beta1, beta2, eps, grad_scale);
+                     beta1, beta2, eps, grad_scale, (int)zero_grad);
   RADNET_CHECK_LAUNCH(ctx, "adam");
   return RADNET_OK;
 }

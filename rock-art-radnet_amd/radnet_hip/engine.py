@@ -362,6 +362,21 @@ class FasterRCNNEngine:
                 self.ctx.check(rc, kind)
 
     @staticmethod
+    def _fuse_bias_grads(ops):
+        """A bias-gradient column sum right after the wgrad of the same layer (same dy, pitch and scale) moves into
+        that wgrad launch (radnet_conv_desc.db): 12 launches of ~7 us less per train step."""
+        out = []
+        for kind, p in ops:
+            if kind == "colsum" and out and out[-1][0] == "wgrad":
+                d = out[-1][1]
+                g, m, n, ld, gs, db, _ = p
+                if d.dy == g and d.ld_dy == ld and d.n == n and (d.gscale or None) == (gs or None) and d.nb * d.oh * d.ow == m:
+                    d.db = db
+                    continue
+            out.append((kind, p))
+        return out
+
+    @staticmethod
     def set_accumulate(ops, flag, prezeroed=False):
         """Gradient write mode of a backward program: flag=False -> overwrite (self-contained; each split wgrad /
         colsum zeroes its own slice), flag=True -> add.  prezeroed=True with flag=False: the caller zeroed the whole
@@ -419,6 +434,7 @@ class FasterRCNNEngine:
         b1.dw, b1.dw_accumulate = c1.dweight.data_ptr(), 1
         bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),
                ("dgrad", b2), ("wgrad", b1), ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
+        bwd = self._fuse_bias_grads(bwd)
         ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
         plan = dict(fwd=[("conv", d1), ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
@@ -438,10 +454,12 @@ class FasterRCNNEngine:
                       self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
         self._run(rp["bwd"])
 
-    def adam(self, arena, grad_scale=1.0):
+    def adam(self, arena, grad_scale=1.0, zero_grad=True):
+        """One Keras-2 Adam step over the arena.  zero_grad: the gradient arena is cleared in the same pass, so the
+        next step's backward accumulates into zeros without a memset (arenas start zeroed, Arena.finalize)."""
         arena.t += 1
         self.ctx.call("radnet_adam_step", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
-                      C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale))
+                      C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0)
 
     def zero_grads(self, arena):
         self.ctx.call("radnet_fill_zero", arena.g, C.c_uint64(arena.n * 4))
@@ -530,6 +548,7 @@ class FasterRCNNEngine:
                 dA = bdesc(B["da"], ca, g_a, f1, g_prev, f3, g_out, B["x"])
                 bwd += [("wgrad", dA), ("colsum", [g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr(), 1]), ("dgrad", dA)]
                 g_out = g_prev
+        bwd = self._fuse_bias_grads(bwd)
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
         self._plans[key] = plan

@@ -205,6 +205,7 @@ class VGG16Engine(FasterRCNNEngine):
         b1.dw, b1.dw_accumulate = f1.dweight.data_ptr(), 1
         bwd_a = [("wgrad", b2), ("colsum", [g2.data_ptr(), R, 4096, 4096, None, f2.dbias.data_ptr(), 1]), ("dgrad", b2)]
         bwd_b = [("wgrad", b1), ("colsum", [g1.data_ptr(), R, 4096, 4096, None, f1.dbias.data_ptr(), 1])]
+        bwd_a, bwd_b = self._fuse_bias_grads(bwd_a), self._fuse_bias_grads(bwd_b)
         plan = dict(R=R, rois=rois, pooled=pooled, fwd1=[("conv", fd1)], fwd2=[("conv", fd2)], bwd=bwd_a + bwd_b, bwd_a=bwd_a, bwd_b=bwd_b,
                     h1=h1, d1=d1, h2=h2, d2=d2, m1=m1, m2=m2, zero=zero, feat=d2, pcls=pcls, pregr=pregr, y1=y1, y2=y2, dz=dz, g2=g2, g1=g1,
                     F=F, fh=fh, fw=fw, keep=keep)

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("dw", C.c_void_p),
         ("ld_dy", C.c_int32), ("ld_dx", C.c_int32), ("ld_dx_add", C.c_int32), ("ld_dx_mask", C.c_int32),
         ("dw_accumulate", C.c_int32),
+        ("db", C.c_void_p),
     ]
 
 
@@ -85,7 +86,7 @@ def load_library():
         "radnet_dense_heads_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32]),
         "radnet_rpn_loss": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
         "radnet_det_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
-        "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32]),
+        "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32]),
         "radnet_affine_vec": (C.c_int, [vp, vp, vp, vp, vp, i64]),
         "radnet_relu_mask": (C.c_int, [vp, vp, vp, i64]),
         "radnet_proposals_ws_bytes": (u64, [i64]),

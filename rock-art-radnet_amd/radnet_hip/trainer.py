@@ -82,7 +82,7 @@ class TrainStep:
             plans.append(bp)
             rps.append(eng.rpn_forward(bp))
         # ---- phase A (host half, overlapped with B) + phase C
-        eng.zero_grads(eng.rpn_arena)                # one memset instead of one per layer
+        # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
         for i in range(nloc):
             ycls, yregr, _ = eng.anchor_targets_finish(tp[i])
             eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
@@ -110,13 +110,9 @@ class TrainStep:
             hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
             eng.pack_roi_batch(P, sel, hp)
             eng.head_forward(hp, training=True)
-            if n_head == 0:
-                eng.zero_grads(eng.head_arena)
             eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
             eng.head_backward(hp, accumulate=True, loss_out=self._det_l[n_head])
             n_head += 1
-        if n_head == 0 and self.world > 1:
-            eng.zero_grads(eng.head_arena)
         if n_head > 0 or self.world > 1:
             self._allreduce(eng.head_arena)
             eng.adam(eng.head_arena, grad_scale=1.0 / ntot)

@@ -23,7 +23,7 @@ def test_conv_desc_layout_matches_header():
     # field order/types are mirrored by hand: catch drift by size (8-byte pointers, 4-byte ints, natural alignment)
     n_ptr = sum(1 for _, t in L.ConvDesc._fields_ if t is ctypes.c_void_p)
     n_i32 = sum(1 for _, t in L.ConvDesc._fields_ if t is ctypes.c_int32)
-    assert (n_ptr, n_i32) == (12, 22)
+    assert (n_ptr, n_i32) == (13, 22)
     assert ctypes.sizeof(L.ConvDesc) >= n_ptr * 8 + n_i32 * 4
 
 

@@ -149,11 +149,15 @@ def test_conv_dgrad_wgrad(ctx, case):
     close(dx.cpu().numpy(), dx_ref)
     close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
     close(db.cpu().numpy(), db_ref)
-    # accumulate mode adds on top
+    # accumulate mode adds on top; the bias gradient rides in the same launch when the descriptor names it
+    db2 = torch.full((cout,), float("nan"), device="cuda")
+    d.db = db2.data_ptr()
     ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
+    close(db2.cpu().numpy(), db_ref)
     d.dw_accumulate = 1
     ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad")
     close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
+    close(db2.cpu().numpy(), 2 * db_ref)
 
 
 def test_wgrad_strided_1x1(ctx):
@@ -301,7 +305,11 @@ def test_adam(ctx):
     for t in range(1, 5):
         g = rs.standard_normal(n).astype(np.float32) * 0.1
         dense.adam_step(p, g, m, v, t, 5e-5)
-        ctx.call("radnet_adam_step", pd, dev(g), md, vd, C.c_int64(n), t, C.c_float(5e-5), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0))
+        gd = dev(g)
+        ctx.call("radnet_adam_step", pd, gd, md, vd, C.c_int64(n), t, C.c_float(5e-5), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0),
+                 t % 2)
+        # zero_grad: the gradient arena is cleared in the same pass (odd t here), left alone otherwise
+        assert np.array_equal(gd.cpu().numpy(), np.zeros(n, np.float32) if t % 2 else g)
     assert np.allclose(pd.cpu().numpy(), p, rtol=0, atol=2e-7)
     assert np.allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-8)
 
