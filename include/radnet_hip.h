@@ -37,6 +37,10 @@ int radnet_create(int device, void* hip_stream, radnet_ctx** out);
 void radnet_destroy(radnet_ctx* ctx);
 const char* radnet_last_error(radnet_ctx* ctx);
 int radnet_sync(radnet_ctx* ctx);
+/* Re-binds the context to another HIP stream (e.g. a stream in capture mode while a sequence of launches is recorded
+ * into a hipGraph; the library performs no allocation, host synchronisation or autotuning for shapes it has already
+ * run, so a recorded sequence replays as is). */
+int radnet_set_stream(radnet_ctx* ctx, void* hip_stream);
 int radnet_version(void);
 /* Scratch the library may use for split-K partial sums (caller-owned, >= bytes). */
 int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);

@@ -43,6 +43,12 @@ extern "C" int radnet_sync(radnet_ctx* ctx) {
   return RADNET_OK;
 }
 
+extern "C" int radnet_set_stream(radnet_ctx* ctx, void* hip_stream) {
+  if (!ctx) return RADNET_ERR_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return RADNET_OK;
+}
+
 extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
   if (!ctx) return RADNET_ERR_ARG;
   ctx->autotune = enable ? 1 : 0;

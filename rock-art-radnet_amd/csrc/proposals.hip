@@ -87,7 +87,17 @@ __device__ __forceinline__ bool suppresses(const double4& pk, double pk_area, co
   const double hh = fmax(0.0, fmin(pk.w, c.w) - fmax(pk.y, c.y));
   const double inter = ww * hh;
   const double uni = pk_area + c_area - inter;
-  return inter / (uni + 1e-6) > thr;
+  const double d = uni + 1e-6;
+  // The reference compares the ROUNDED quotient with thr.  An fp64 division is a ~40-instruction sequence here and
+  // this test runs picks x candidates times, so decide without it whenever the outcome cannot depend on rounding:
+  // with d > 0, thr > 0 and |inter - thr*d| beyond a 2^-40 relative margin (the products and the quotient each
+  // carry < 2^-52), fl(inter/d) > thr  <=>  inter > thr*d.  Everything inside the margin takes the division.
+  if (d > 0.0 && thr > 0.0) {
+    const double t = thr * d;
+    if (inter > t * (1.0 + 0x1p-40)) return true;
+    if (inter < t * (1.0 - 0x1p-40)) return false;
+  }
+  return inter / d > thr;
 }
 
 constexpr int kMaxPicks = 1024;
@@ -116,18 +126,29 @@ __global__ void __launch_bounds__(1024) nms_kernel(const unsigned long long* __r
   if (tid == 0) s_npicks = 0;
   __syncthreads();
 
+  // The chunk's candidates come through two dependent global reads (sorted key -> box): the reads of chunk c+1 are
+  // issued before chunk c is processed and land while its three phases run, instead of ~1.5 us of exposed latency
+  // per chunk on a single workgroup.
+  int pre_id = 0;
+  double4 pre_box = make_double4(0.0, 0.0, 0.0, 0.0);
+  auto fetch = [&](int base) {
+    if (tid < 64 && base + tid < n_valid) {
+      pre_id = (int)(keys[base + tid] & 0xFFFFFFFFull);
+      pre_box = boxes[pre_id];
+    }
+  };
+  fetch(0);
   for (int base = 0; base < n_valid; base += 64) {
     const int nc = min(64, n_valid - base);
     if (tid < 64) {
       if (tid < nc) {
-        const int id = (int)(keys[base + tid] & 0xFFFFFFFFull);
-        const double4 b = boxes[id];
-        cand_idx[tid] = id;
-        cand_box[tid] = b;
-        cand_area[tid] = (b.z - b.x) * (b.w - b.y);
+        cand_idx[tid] = pre_id;
+        cand_box[tid] = pre_box;
+        cand_area[tid] = (pre_box.z - pre_box.x) * (pre_box.w - pre_box.y);
       }
       if (tid < 2) sup[tid] = 0u;
     }
+    fetch(base + 64);
     __syncthreads();
     const int npicks = s_npicks;
     // (1) candidates vs existing picks: lane = candidate, wave = slice of the pick list

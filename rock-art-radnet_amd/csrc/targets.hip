@@ -88,7 +88,16 @@ __global__ void __launch_bounds__(256) anchor_targets_kernel(AnchorArgs g, uint8
   const int ar = o / (g.fh * g.fw);
   const int ri = ar % g.nr, si = ar / g.nr;
   const AnchorBox b = anchor_box(g, si, ri, ix, jy);
-  if (!b.inside || g.g == 0) return;                       // label write sits inside the GT loop (utils.py:723-738)
+  // every anchor owns one (valid, overlap, regr[4]) cell and writes it, zeros included: no memset of the maps
+  const int ch = ri + g.nr * si;
+  const size_t chw = ((size_t)ch * g.fh + jy) * g.fw + ix;
+  double* r = regr + ((size_t)jy * g.fw + ix) * 4 * A + 4 * ch;
+  if (!b.inside || g.g == 0) {                             // label write sits inside the GT loop (utils.py:723-738)
+    valid[chw] = 0;
+    overlap[chw] = 0;
+    r[0] = r[1] = r[2] = r[3] = 0.0;
+    return;
+  }
   bool pos = false;
   double best_loc = 0.0;
   int best_k = -1;
@@ -106,15 +115,18 @@ __global__ void __launch_bounds__(256) anchor_targets_kernel(AnchorArgs g, uint8
       if (v > best_loc) { best_loc = v; best_k = k; }
     }
   }
-  const int ch = ri + g.nr * si;
-  const size_t chw = ((size_t)ch * g.fh + jy) * g.fw + ix;
   valid[chw] = 1;
   overlap[chw] = pos ? 1 : 0;
-  if (pos) {
-    double t[4];
-    deltas(sgt[best_k][0], sgt[best_k][1], sgt[best_k][2], sgt[best_k][3], b, t);
-    double* r = regr + ((size_t)jy * g.fw + ix) * 4 * A + 4 * ch;
-    r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+  double t[4] = {0.0, 0.0, 0.0, 0.0};
+  if (pos) deltas(sgt[best_k][0], sgt[best_k][1], sgt[best_k][2], sgt[best_k][3], b, t);
+  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+}
+
+// per-GT scratch of the launch above (best-anchor keys, positive counts): one small launch instead of two memsets
+__global__ void anchor_clear_kernel(unsigned long long* __restrict__ best, int* __restrict__ n_for_gt, int g) {
+  for (int k = threadIdx.x; k < g; k += blockDim.x) {
+    best[k] = 0ull;
+    n_for_gt[k] = 0;
   }
 }
 
@@ -256,12 +268,14 @@ extern "C" int radnet_anchor_targets(radnet_ctx* ctx, const double* gt, const in
   for (int i = 0; i < nr; ++i) { a.ratios[i][0] = anchor_ratios_host[2 * i]; a.ratios[i][1] = anchor_ratios_host[2 * i + 1]; }
   const int A = ns * nr;
   const size_t n = (size_t)A * fw * fh;
-  RADNET_CHECK_HIP(ctx, hipMemsetAsync(valid, 0, n, ctx->stream));
-  RADNET_CHECK_HIP(ctx, hipMemsetAsync(overlap, 0, n, ctx->stream));
-  RADNET_CHECK_HIP(ctx, hipMemsetAsync(regr, 0, n * 4 * sizeof(double), ctx->stream));
-  if (g == 0) return RADNET_OK;
-  RADNET_CHECK_HIP(ctx, hipMemsetAsync(scratch, 0, (size_t)g * 8, ctx->stream));
-  RADNET_CHECK_HIP(ctx, hipMemsetAsync(n_for_gt, 0, (size_t)g * 4, ctx->stream));
+  if (g == 0) {              // no ground truth: nothing is valid (utils.py:723-738 never runs)
+    RADNET_CHECK_HIP(ctx, hipMemsetAsync(valid, 0, n, ctx->stream));
+    RADNET_CHECK_HIP(ctx, hipMemsetAsync(overlap, 0, n, ctx->stream));
+    RADNET_CHECK_HIP(ctx, hipMemsetAsync(regr, 0, n * 4 * sizeof(double), ctx->stream));
+    return RADNET_OK;
+  }
+  hipLaunchKernelGGL(anchor_clear_kernel, dim3(1), dim3(256), 0, ctx->stream, (unsigned long long*)scratch, n_for_gt, g);
+  RADNET_CHECK_LAUNCH(ctx, "anchor_clear");
   hipLaunchKernelGGL(anchor_targets_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, a, valid, overlap, regr,
                      (unsigned long long*)scratch, n_for_gt);
   RADNET_CHECK_LAUNCH(ctx, "anchor_targets");

@@ -12,6 +12,7 @@ Graph restated from the reference (never imported):
   step   train.py:288-402                              RPN train -> re-predict -> propose/label/sample -> head train
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -115,9 +116,19 @@ class FasterRCNNEngine:
         self.dense_ld = 32 if self.nc + self.nreg <= 32 else 64
         self._build_layers()
         self._plans = {}
+        self._graphs = {}
+        self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
         self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
+        # second context on a side stream: with RADNET_OVERLAP_WGRAD=1 the weight-gradient GEMMs of a backward program
+        # run there, beside the dgrad chain they hang off (they only feed the optimizer).  Measured on MI355X at
+        # 1000x600: 3.48 ms/step with the overlap, 3.41 without -- each GEMM is tuned (tile, K slices) to fill the
+        # chip alone, and two of them in flight only compete for LDS / L2.  Kept as an option, off by default.
+        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self.ctx2 = L.Context(device_index, stream_handle=self.side_stream.cuda_stream)
+        self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
+        self.overlap_wgrad = os.environ.get("RADNET_OVERLAP_WGRAD", "0") == "1"
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
         self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)
@@ -341,13 +352,55 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
-    def _run(self, ops):
+    def _run(self, ops, overlap=False):
+        """Run a layer program (overlap: its wgrad launches go to the side stream, see __init__).  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
+        autotunes every new GEMM shape and builds its work-unit tables -- the launch sequence is recorded into a
+        hipGraph and replayed: ~20 us of host time per launch (ctypes + hipLaunchKernel) become one graph launch, and
+        the host thread stays ahead of the GPU (tools/host_timeline.py).  Keyed by the program and the gradient
+        write modes of its wgrad descriptors (set_accumulate edits them in place)."""
+        overlap = overlap and self.overlap_wgrad and not self.ctx.timing_on      # timed launches run one at a time
+        key = (id(ops), overlap, tuple(p.dw_accumulate for kind, p in ops if kind == "wgrad"))
+        ent = self._graphs.get(key)
+        if ent is None:
+            # first run of this program: every new GEMM shape is measured here, so launches run one at a time
+            self._graphs[key] = [ops, None]          # holds `ops` so its id stays unique
+            return self._run_eager(ops, overlap, isolate=True)
+        if not self.use_graphs or self.ctx.timing_on or torch.cuda.is_current_stream_capturing():
+            return self._run_eager(ops, overlap)
+        if ent[1] is None:
+            g = torch.cuda.CUDAGraph()
+            prev = self.ctx.stream_handle
+            with torch.cuda.graph(g):
+                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                try:
+                    self._run_eager(ops, overlap)
+                finally:
+                    self.ctx.set_stream(prev)
+            ent[1] = g
+        ent[1].replay()
+
+    def _run_eager(self, ops, overlap=False, isolate=False):
         lib, h = self.lib, self.ctx.h
+        forked = False
         for kind, p in ops:
             if kind == "conv":
                 rc = lib.radnet_conv_fwd(h, C.byref(p))
             elif kind == "dgrad":
                 rc = lib.radnet_conv_dgrad(h, C.byref(p))
+            elif kind == "wgrad" and overlap:
+                # everything enqueued so far on the main stream produced this launch's inputs; gradient buffers are
+                # written once per backward pass, so nothing the main stream does later can overwrite them
+                ev = torch.cuda.Event()
+                ev.record()
+                self.side_stream.wait_event(ev)
+                if isolate:
+                    torch.cuda.current_stream().synchronize()
+                rc = lib.radnet_conv_wgrad(self.ctx2.h, C.byref(p))
+                if rc != 0:
+                    self.ctx2.check(rc, kind)
+                if isolate:
+                    self.side_stream.synchronize()
+                forked = True
             elif kind == "wgrad":
                 rc = lib.radnet_conv_wgrad(h, C.byref(p))
             elif kind == "maxpool":
@@ -360,6 +413,8 @@ class FasterRCNNEngine:
                 raise L.RadnetError("unknown op " + kind)
             if rc != 0:
                 self.ctx.check(rc, kind)
+        if forked:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     @staticmethod
     def _fuse_bias_grads(ops):
@@ -393,8 +448,21 @@ class FasterRCNNEngine:
         """uint8 BGR HWC host image -> preprocessed fp32 NHWC(4) on device (RADNet.py:83-87)."""
         H, W = img_bgr_u8.shape[:2]
         plan = self._plan_base(1, H, W, slot)
-        raw = torch.from_numpy(np.ascontiguousarray(img_bgr_u8)).to(self.dev)
-        self.ctx.call("radnet_preprocess_bgr", raw, H, W, 4, plan["x"])
+        # through a pinned staging buffer: a pageable H2D copy blocks the host thread for ~1 ms per 1.8 MB panel,
+        # the pinned one is an asynchronous DMA behind a 0.1 ms memcpy (a pinned torch tensor skips the memcpy too)
+        if "raw" not in plan:
+            plan["raw"] = torch.empty(H, W, 3, dtype=torch.uint8, device=self.dev)
+            plan["h_raw"] = torch.empty(H, W, 3, dtype=torch.uint8).pin_memory()
+            plan["raw_free"] = torch.cuda.Event()
+        if isinstance(img_bgr_u8, torch.Tensor) and img_bgr_u8.is_pinned():
+            src = img_bgr_u8
+        else:
+            plan["raw_free"].synchronize()         # the previous DMA out of the staging buffer has finished
+            src = plan["h_raw"]
+            np.copyto(src.numpy(), img_bgr_u8)     # NumPy's single-threaded memcpy (a torch CPU copy_ fans out to OpenMP)
+        plan["raw"].copy_(src, non_blocking=True)
+        plan["raw_free"].record()
+        self.ctx.call("radnet_preprocess_bgr", plan["raw"], H, W, 4, plan["x"])
         return plan
 
     def upload_preprocessed(self, X):
@@ -452,7 +520,7 @@ class FasterRCNNEngine:
         """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
         self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,
                       self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
-        self._run(rp["bwd"])
+        self._run(rp["bwd"], overlap=True)
 
     def adam(self, arena, grad_scale=1.0, zero_grad=True):
         """One Keras-2 Adam step over the arena.  zero_grad: the gradient arena is cleared in the same pass, so the
@@ -569,7 +637,7 @@ class FasterRCNNEngine:
         self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
                       self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
-        self._run(hp["bwd"])
+        self._run(hp["bwd"], overlap=True)
 
     # ------------------------------------------------------------------------------------------ targets
     def upload_gt(self, gt_boxes, gt_is_bg, gt_cls):

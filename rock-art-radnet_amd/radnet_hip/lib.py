@@ -65,6 +65,7 @@ def load_library():
         "radnet_destroy": (None, [vp]),
         "radnet_last_error": (C.c_char_p, [vp]),
         "radnet_sync": (C.c_int, [vp]),
+        "radnet_set_stream": (C.c_int, [vp, vp]),
         "radnet_version": (C.c_int, []),
         "radnet_set_workspace": (C.c_int, [vp, vp, u64]),
         "radnet_set_autotune": (C.c_int, [vp, C.c_int]),
@@ -138,6 +139,8 @@ class Context:
             raise RadnetError("radnet_create failed with code %d (needs a gfx950 device)" % rc)
         self.h = h
         self.device_index = device_index
+        self.stream_handle = stream_handle
+        self.timing_on = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -162,9 +165,14 @@ class Context:
     def sync(self):
         self.check(self.lib.radnet_sync(self.h), "radnet_sync")
 
+    def set_stream(self, stream_handle):
+        self.check(self.lib.radnet_set_stream(self.h, C.c_void_p(stream_handle)), "radnet_set_stream")
+        self.stream_handle = stream_handle
+
     # timing of the GEMM-class launches (HIP events on the ctx stream)
     def timing(self, enable):
         self.check(self.lib.radnet_timing_enable(self.h, 1 if enable else 0), "timing_enable")
+        self.timing_on = bool(enable)
 
     def timing_reset(self):
         self.check(self.lib.radnet_timing_reset(self.h), "timing_reset")

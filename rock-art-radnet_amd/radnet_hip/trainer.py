@@ -47,6 +47,7 @@ class TrainStep:
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
+        self.host_marks = None      # set to [] to record (label, perf_counter) at the host-side phase boundaries
         dev = eng.dev
         self._rpn_l = torch.zeros(64, 2, dtype=torch.float32, device=dev)     # per-image loss slots (logging)
         self._det_l = torch.zeros(64, 3, dtype=torch.float32, device=dev)
@@ -71,24 +72,36 @@ class TrainStep:
         C = eng.C
         nloc = len(batch)
         ntot = nloc * self.world
+        marks = self.host_marks
+
+        def mark(label):
+            if marks is not None:
+                import time
+                marks.append((label, time.perf_counter()))
+
+        mark("start")
         # ---- phase A (device half) + phase B, all asynchronous
         tp, plans, rps = [], [], []
         for i, s in enumerate(batch):
             H, W = s["img"].shape[:2]
             tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=i))
+        mark("A: anchor kernels enqueued")
         for i, s in enumerate(batch):
             bp = eng.upload_image(s["img"], slot=i)
             eng.base_forward(bp)
             plans.append(bp)
             rps.append(eng.rpn_forward(bp))
+        mark("B: upload + base + rpn forward enqueued")
         # ---- phase A (host half, overlapped with B) + phase C
         # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
         for i in range(nloc):
             ycls, yregr, _ = eng.anchor_targets_finish(tp[i])
+            mark("A: label maps on host, subsampled, packed")
             eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
             eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[i])
         self._allreduce(eng.rpn_arena)
         eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
+        mark("C: rpn backward + adam enqueued")
         # ---- phase D: re-predict with updated weights, propose, label, sample, head train
         n_head = 0
         for i, bp in enumerate(plans):
@@ -97,13 +110,16 @@ class TrainStep:
             eng._run(rp["fwd"])
             R, Rn = eng.proposals(rp, overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
+            mark("D: rpn re-predict + proposals + roi targets enqueued")
             P, cls, n = eng.roi_targets(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)      # one sync
+            mark("D: roi classes on host (GPU drained)")
             kept = np.nonzero(cls >= 0)[0]
             if n <= 0 or len(kept) == 0:                           # calc_iou -> None: the reference skips the head step
                 self.skipped_head_steps += 1
                 continue
             sel_k, _ = E.select_samples(cls[kept], eng.bg, C.n_rois)
             sel = kept[np.asarray(sel_k, dtype=np.int64)]
+            mark("D: samples selected")
             if self.capture is not None:
                 self.capture.append(dict(pred=rp["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(), keep=(cls >= 0).copy(),
                                          cls=cls.copy(), sel_kept=list(sel_k)))
@@ -117,6 +133,7 @@ class TrainStep:
             self._allreduce(eng.head_arena)
             eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
             eng.refresh_head_shift()
+        mark("D: head forward + backward + adam enqueued")
         self.last = (nloc, n_head)
         return self
 
