@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--tune-cache", default=None,
+                    help="file with measured GEMM launch choices: loaded when present (no trial launches), written after warm-up otherwise")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +102,9 @@ def main():
     eng = FasterRCNNEngine(C, device_index=local_rank)
     eng.set_weights(synth.synthetic_weights(seed=3))
     ts = TrainStep(eng, world_size=world)
+    have_cache = args.tune_cache is not None and os.path.exists(args.tune_cache)
+    if have_cache:
+        eng.load_tuning(args.tune_cache)
     batch = make_batch(rank, args.per_gpu_batch, args.height, args.width)
     np.random.seed(64 + rank)
 
@@ -111,6 +116,8 @@ def main():
     for _ in range(args.warmup):
         ts.step(batch)
     barrier()
+    if args.tune_cache is not None and not have_cache and rank == 0:
+        eng.save_tuning(args.tune_cache)
     skipped0 = ts.skipped_head_steps
     t0 = time.perf_counter()
     for _ in range(args.steps):

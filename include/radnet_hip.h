@@ -50,6 +50,10 @@ int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);
  * tunes the whole layer program.  radnet_tuned_shapes() returns the number of cached shapes. */
 int radnet_set_autotune(radnet_ctx* ctx, int enable);
 int radnet_tuned_shapes(radnet_ctx* ctx);
+/* Persist / restore the measured choices (text, one shape per line).  A context that loaded a table runs no trial
+ * launches for the shapes in it: restarts skip the tuning step, and a profiler sees steady-state launches only. */
+int radnet_tune_save(radnet_ctx* ctx, const char* path);
+int radnet_tune_load(radnet_ctx* ctx, const char* path);
 /* Test hook: force every following conv GEMM launch to use output tile (tile_a x tile_b in {64,128}) and `slices` K
  * slices per tile (negative = same slices with the XCD-aware workgroup order); tile_a = 0 switches it off. */
 int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);

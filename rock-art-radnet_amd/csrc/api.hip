@@ -57,6 +57,39 @@ extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
 
 extern "C" int radnet_tuned_shapes(radnet_ctx* ctx) { return ctx ? (int)ctx->tuned.size() : -1; }
 
+extern "C" int radnet_tune_save(radnet_ctx* ctx, const char* path) {
+  if (!ctx || !path) return RADNET_ERR_ARG;
+  FILE* f = fopen(path, "w");
+  if (!f) RADNET_FAIL(ctx, RADNET_ERR_ARG, "tune_save: cannot open %s", path);
+  fprintf(f, "# radnet tuned GEMM launch shapes v1: kind m n k c npos stride | tile_a tile_b slices ms\n");
+  for (const auto& kv : ctx->tuned)
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %.6f\n", kv.first.kind, kv.first.m, kv.first.n, kv.first.k, kv.first.c, kv.first.npos,
+            kv.first.stride, kv.second.a, kv.second.b, kv.second.splits, (double)kv.second.ms);
+  fclose(f);
+  return RADNET_OK;
+}
+
+extern "C" int radnet_tune_load(radnet_ctx* ctx, const char* path) {
+  if (!ctx || !path) return RADNET_ERR_ARG;
+  FILE* f = fopen(path, "r");
+  if (!f) RADNET_FAIL(ctx, RADNET_ERR_ARG, "tune_load: cannot open %s", path);
+  char line[256];
+  int n = 0;
+  while (fgets(line, sizeof(line), f)) {
+    if (line[0] == '#') continue;
+    radnet_shape_key k{};
+    radnet_tuned t{};
+    double ms = 0.0;
+    if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %lf", &k.kind, &k.m, &k.n, &k.k, &k.c, &k.npos, &k.stride, &t.a, &t.b, &t.splits, &ms) != 11) continue;
+    if ((t.a != 64 && t.a != 128) || (t.b != 64 && t.b != 128) || t.splits == 0 || t.splits > 64 || t.splits < -64) continue;
+    t.ms = (float)ms;
+    ctx->tuned[k] = t;
+    ++n;
+  }
+  fclose(f);
+  return n >= 0 ? RADNET_OK : RADNET_ERR_ARG;
+}
+
 extern "C" int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices) {
   if (!ctx) return RADNET_ERR_ARG;
   if (tile_a != 0 && ((tile_a != 64 && tile_a != 128) || (tile_b != 64 && tile_b != 128)))

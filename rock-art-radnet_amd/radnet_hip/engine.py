@@ -352,6 +352,15 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
+    def save_tuning(self, path):
+        """Write the measured GEMM launch choices of this engine (main context) to a text file."""
+        self.ctx.check(self.lib.radnet_tune_save(self.ctx.h, path.encode()), "radnet_tune_save")
+
+    def load_tuning(self, path):
+        """Restore choices written by save_tuning: no trial launches for the shapes in the file."""
+        for c in (self.ctx, self.ctx2):
+            c.check(self.lib.radnet_tune_load(c.h, path.encode()), "radnet_tune_load")
+
     def _run(self, ops, overlap=False):
         """Run a layer program (overlap: its wgrad launches go to the side stream, see __init__).  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
         autotunes every new GEMM shape and builds its work-unit tables -- the launch sequence is recorded into a

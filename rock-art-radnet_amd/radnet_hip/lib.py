@@ -70,6 +70,8 @@ def load_library():
         "radnet_set_workspace": (C.c_int, [vp, vp, u64]),
         "radnet_set_autotune": (C.c_int, [vp, C.c_int]),
         "radnet_tuned_shapes": (C.c_int, [vp]),
+        "radnet_tune_save": (C.c_int, [vp, C.c_char_p]),
+        "radnet_tune_load": (C.c_int, [vp, C.c_char_p]),
         "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
