@@ -78,6 +78,7 @@ class RADNet():
         stride = C.rpn_stride
         std = C.classifier_regr_std
         bboxes, probs = {}, {}
+        chunks = []
         for start in range(0, R.shape[0], k):
             chunk = R[start:start + k, :]
             if chunk.shape[0] < k:
@@ -85,8 +86,18 @@ class RADNet():
                 padded[:chunk.shape[0]] = chunk
                 padded[chunk.shape[0]:] = chunk[0]
                 chunk = padded
-            ROIs = np.expand_dims(chunk, axis=0)
-            P_cls, P_regr = self.model_detector.predict([feature_map, ROIs])
+            chunks.append(np.expand_dims(chunk, axis=0))
+        # The reference's Keras detector is built for exactly n_rois RoIs, hence its 15 calls per tile.  The HIP
+        # detector takes any count (every RoI is independent under TimeDistributed), so all chunks -- padding rows
+        # included, they are decoded too -- go through ONE head pass: GEMM M = 14 700 instead of 15 x 980.
+        if chunks and getattr(self.model_detector, "accepts_any_roi_count", False):
+            allr = np.concatenate(chunks, axis=1)
+            pc, pr = self.model_detector.predict([feature_map, allr])
+            outs = [(pc[:, i * k:(i + 1) * k], pr[:, i * k:(i + 1) * k]) for i in range(len(chunks))]
+        else:
+            outs = None
+        for ci, ROIs in enumerate(chunks):
+            P_cls, P_regr = outs[ci] if outs is not None else self.model_detector.predict([feature_map, ROIs])
             for ii in range(P_cls.shape[1]):
                 scores = P_cls[0, ii, :]
                 best = int(np.argmax(scores))

@@ -185,6 +185,7 @@ class ClassifierModel(_ModelBase):
 
 class DetectorModel(_ModelBase):
     """Model([feature_map_input, roi_input], detector_layers) (RADNet.py:761-770)."""
+    accepts_any_roi_count = True        # RADNet.apply_spatial_pyramid_pooling then sends all RoIs of a tile at once
 
     def _features(self, F):
         import torch
