@@ -178,14 +178,14 @@ __global__ void __launch_bounds__(1024) nms_kernel(const unsigned long long* __r
       unsigned long long alive = ~(((unsigned long long)sup[1] << 32) | sup[0]);
       if (nc < 64) alive &= (1ull << nc) - 1ull;
       int np = npicks;
-      for (int j = 0; j < nc && np < max_boxes; ++j) {
-        if ((alive >> j) & 1ull) {
-          pick_box[np] = cand_box[j];
-          pick_area[np] = cand_area[j];
-          pick_idx[np] = cand_idx[j];
-          ++np;
-          alive &= ~mat[j];
-        }
+      while (alive != 0ull && np < max_boxes) {          // visits the survivors only, in candidate order
+        const int j = __ffsll((long long)alive) - 1;
+        pick_box[np] = cand_box[j];
+        pick_area[np] = cand_area[j];
+        pick_idx[np] = cand_idx[j];
+        ++np;
+        alive &= ~mat[j];                                 // mat[j] only has bits above j
+        alive &= ~(1ull << j);
       }
       s_npicks = np;
     }
