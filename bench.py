@@ -122,6 +122,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts.step(batch)
+    ts.flush()                       # multi-GPU: the last step's deferred head update belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if ts.skipped_head_steps != skipped0:

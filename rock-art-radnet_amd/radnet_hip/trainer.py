@@ -38,12 +38,29 @@ def allreduce_grad_arena(flat, world, group=None):
     return 1.0 / world
 
 
+def allreduce_grad_arena_start(flat, world, group=None):
+    """The same exchange, asynchronous: returns a handle whose wait() orders the CURRENT stream after the reduction
+    (None on a single rank).  The collective runs on the backend's own stream, beside whatever is enqueued next."""
+    if world > 1:
+        import torch.distributed as dist
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 class TrainStep:
 
-    def __init__(self, eng, dist_group=None, world_size=1):
+    def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
+        """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
+        of the two exchanges) is started asynchronously after the head backward and Adam #2 is applied just before
+        the NEXT step's head forward -- the first point that reads head weights (the base is frozen and the RPN has
+        its own optimizer), so the update order the reference defines is unchanged while the exchange hides under
+        the next image's anchor labelling, base forward and RPN phases.  Call flush() after the last
+        step."""
         self.eng = eng
         self.world = world_size
         self.group = dist_group
+        self.defer_head_update = (world_size > 1) if defer_head_update is None else bool(defer_head_update)
+        self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
@@ -54,6 +71,20 @@ class TrainStep:
 
     def _allreduce(self, arena):
         allreduce_grad_arena(arena.g, self.world, self.group)
+
+    def _finish_head_update(self):
+        if self._head_pending is None:
+            return
+        work, ntot = self._head_pending
+        self._head_pending = None
+        if work is not None:
+            work.wait()
+        self.eng.adam(self.eng.head_arena, grad_scale=1.0 / ntot)
+        self.eng.refresh_head_shift()
+
+    def flush(self):
+        """Apply a head update still in flight (deferred mode); no-op otherwise."""
+        self._finish_head_update()
 
     def _gt(self, s):
         """Device copy of a sample's ground truth (cached on the sample: uploaded once)."""
@@ -125,14 +156,19 @@ class TrainStep:
                                          cls=cls.copy(), sel_kept=list(sel_k)))
             hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
             eng.pack_roi_batch(P, sel, hp)
+            self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
             eng.head_forward(hp, training=True)
             eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
             eng.head_backward(hp, accumulate=True, loss_out=self._det_l[n_head])
             n_head += 1
         if n_head > 0 or self.world > 1:
-            self._allreduce(eng.head_arena)
-            eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
-            eng.refresh_head_shift()
+            self._finish_head_update()               # only still pending when every local image skipped its head phase
+            if self.defer_head_update:
+                self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group), ntot)
+            else:
+                self._allreduce(eng.head_arena)
+                eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
+                eng.refresh_head_shift()
         mark("D: head forward + backward + adam enqueued")
         self.last = (nloc, n_head)
         return self
