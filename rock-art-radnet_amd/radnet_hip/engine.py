@@ -379,13 +379,22 @@ class FasterRCNNEngine:
         if ent[1] is None:
             g = torch.cuda.CUDAGraph()
             prev = self.ctx.stream_handle
-            with torch.cuda.graph(g):
-                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-                try:
-                    self._run_eager(ops, overlap)
-                finally:
-                    self.ctx.set_stream(prev)
-            ent[1] = g
+            try:
+                # thread_local: other threads of the process (the collective backend's watchdog polling its events)
+                # must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                    try:
+                        self._run_eager(ops, overlap)
+                    finally:
+                        self.ctx.set_stream(prev)
+                ent[1] = g
+            except Exception as e:      # nothing recorded has executed: run this program eagerly, now and from here on
+                import sys
+                sys.stderr.write("radnet: hipGraph capture failed (%s); layer programs run eagerly\n" % (e,))
+                self.ctx.set_stream(prev)
+                self.use_graphs = False
+                return self._run_eager(ops, overlap)
         ent[1].replay()
 
     def _run_eager(self, ops, overlap=False, isolate=False):
