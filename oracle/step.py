@@ -66,6 +66,55 @@ class OracleTrainer:
         return [l_rpn[1], l_rpn[2], l_det[1], l_det[2], l_det[3]]
 
 
+def _acc(total, g):
+    if total is None:
+        return {n: {k: v.astype(np.float64).copy() for k, v in d.items()} for n, d in g.items()}
+    for n, d in g.items():
+        for k, v in d.items():
+            total[n][k] += v
+    return total
+
+
+def _scaled(total, f):
+    return {n: {k: v * f for k, v in d.items()} for n, d in total.items()}
+
+
+def step_batch(trainer, samples, details=None, override_R=None):
+    """BASELINE cfg 4 semantics (the reference is batch-1 only, the build defines the mini-batch): every
+    image is an independent reference iteration on the SAME weights, each optimizer applies once with the MEAN
+    gradient over all B images (an image whose classifier phase is skipped contributes zero to that mean).
+    NumPy-RNG order: anchor subsampling of image 0..B-1, then RoI sample selection of image 0..B-1.
+    Returns one loss list per image, as OracleTrainer.step does."""
+    t = trainer
+    C, P, B = t.C, t.P, len(samples)
+    tg = [t.targets(s) for s in samples]
+    Fs = [dense.base_forward(P, dense.preprocess_caffe_bgr(s["img"])) for s in samples]
+    out, g_sum = [], None
+    for F, (yc, yr) in zip(Fs, tg):
+        l, g = dense.rpn_losses_and_grads(P, F, yc.astype(np.float32), yr.astype(np.float32), t.A, t.keras2_bce)
+        out.append([l[1], l[2], None, None, None])
+        g_sum = _acc(g_sum, g)
+    t.opt_rpn.apply(P, _scaled(g_sum, 1.0 / B))
+    h_sum = None
+    for i, (s, F) in enumerate(zip(samples, Fs)):
+        p, r, _ = dense.rpn_forward(P, F)
+        R = glue.rpn_to_roi(p, r, C, use_regr=True, overlap_thresh=0.7, max_boxes=300) if override_R is None else override_R[i]
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in s["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        gcls = np.array([C.class_mapping[b["class"]] for b in s["bboxes"]])
+        X2, Y1, Y2, _ = glue.roi_targets(R, gt, gcls, s["width"], s["height"], C)
+        if X2 is None:
+            continue
+        sel, _ = glue.select_samples(Y1, C.n_rois)
+        l, g = dense.head_losses_and_grads(P, F, X2[0, sel].astype(np.float32), Y1[:, sel].astype(np.float32), Y2[:, sel].astype(np.float32), t.nc)
+        out[i][2:] = [l[1], l[2], l[3]]
+        h_sum = _acc(h_sum, g)
+        if details is not None:
+            details.append(dict(sel=sel, Y1=Y1))
+    if h_sum is not None:
+        t.opt_head.apply(P, _scaled(h_sum, 1.0 / B))
+    return out
+
+
 def rpn_only_forward(P, img_bgr_u8):
     """cfg 1: model_rpn.predict on one image -> (cls, regr, F)."""
     F = dense.base_forward(P, dense.preprocess_caffe_bgr(img_bgr_u8))

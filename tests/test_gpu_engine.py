@@ -200,3 +200,51 @@ def test_full_train_step_vs_oracle():
             assert big.sum() > 0
             assert np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
             assert np.abs(d_gpu).max() <= 5e-5 * 1.0001
+
+
+def test_cfg4_two_images_per_step_vs_oracle():
+    """BASELINE config 4 semantics on one GPU: two images per step, each an independent reference iteration on the same
+    weights, both optimizers applied once with the mean gradient (what the data-parallel ranks compute together).
+    Losses per image, RNG consumption and the first Adam step's weight deltas against the oracle's step_batch."""
+    import copy
+    from faster_rcnn.config import Config
+    from oracle import dense, step as ostep
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size = 300
+    P = dense.init_params(seed=3)
+    eng = FasterRCNNEngine(C)
+    eng.set_weights(P)
+    batch = []
+    for i in range(2):
+        meta = synth.synthetic_gt(20 + i, n=6, src_w=1000, src_h=600, smin=60, smax=300)
+        batch.append(dict(img=synth.synthetic_panel(10 + i, 300, 500), bboxes=meta["bboxes"], width=1000, height=600))
+    np.random.seed(64)
+    ts = TrainStep(eng)
+    ts.capture = []
+    ts.step(batch)
+    got = ts.losses()
+    rng_gpu = np.random.randint(0, 2 ** 31 - 1)
+    w_after = eng.get_weights()
+    assert got["n_head"] == 2 and len(ts.capture) == 2
+
+    np.random.seed(64)
+    ot = ostep.OracleTrainer(C, copy.deepcopy(P))
+    det = []
+    ref = ostep.step_batch(ot, batch, details=det, override_R=[c["R"] for c in ts.capture])
+    assert np.random.randint(0, 2 ** 31 - 1) == rng_gpu                 # same draws from the global NumPy stream
+    for c, d in zip(ts.capture, det):
+        assert c["sel_kept"] == d["sel"]
+    r = np.array([[x for x in row] for row in ref], dtype=np.float64)
+    assert abs(got["rpn_cls"] - r[:, 0].mean()) < 1e-3 * abs(r[:, 0].mean())
+    assert abs(got["rpn_regr"] - r[:, 1].mean()) < 1e-3 * abs(r[:, 1].mean()) + 1e-6
+    assert abs(got["det_cls"] - r[:, 2].mean()) < 2e-3 * abs(r[:, 2].mean())
+    assert abs(got["det_regr"] - r[:, 3].mean()) < 2e-3 * abs(r[:, 3].mean()) + 1e-5
+    for name in ("rpn_conv1", "rpn_out_regress", "res5a_branch2a", "res5c_branch2c", "dense_regress_7"):
+        for k in ("kernel", "bias"):
+            d_ref, d_gpu = ot.P[name][k] - P[name][k], w_after[name][k] - P[name][k]
+            big = np.abs(d_ref) > 0.9 * 5e-5                               # first Adam step: |delta| ~ lr where the gradient is not tiny
+            assert big.sum() > 0
+            assert np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
