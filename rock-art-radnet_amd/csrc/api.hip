@@ -30,6 +30,8 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
     if (kv.second.d_units) (void)hipFree(kv.second.d_units);
     if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
   }
+  for (auto& kv : ctx->row_tables)
+    if (kv.second) (void)hipFree(kv.second);
   if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
   if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
   delete ctx;

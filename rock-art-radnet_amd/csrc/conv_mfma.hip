@@ -86,6 +86,11 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
   f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int2 buf_load2i(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  return make_int2((int)v.x, (int)v.y);
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
@@ -614,8 +619,7 @@ struct WgradArgs {
   int ld_dy, ldw;
   int mt_per_split;
   int atomic;
-  unsigned long long magic_ohow, magic_ow;
-  int OHOW;
+  const int2* rowtab;    // [M] {byte offset of the row's window origin, ih0 | iw0 << 16}, see get_row_table
   unsigned x_bytes, dy_bytes;
 };
 
@@ -660,37 +664,56 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   // FixedBatchNormalization shift: d/db = sum over pixels of the scaled output gradient)
   const bool do_bias = g.db != nullptr && blockIdx.x == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_tile = [&](int mt) {
+
+  // Row table (host-built once per conv geometry, get_row_table): rowtab[m] = {byte offset of (image, ih0, iw0,
+  // channel 0) -- possibly negative in the halo --, ih0 & 0xFFFF | iw0 << 16}.  The reduction index m advances by 32
+  // per tile, so decoding m -> (image, oh, ow) inside the loop cost two multiply-high divisions and three 16-cycle
+  // multiplies per load; with the table a load is two adds and two range compares.  The entries of tile t+2 are
+  // fetched while tile t is multiplied, one tile ahead of the loads that use them.
+  const __amdgpu_buffer_rsrc_t rtab = make_rsrc(g.rowtab, (unsigned)g.M * 8u);
+  const int tap_off = ((kh * g.W + kw) * g.C + cbase + a_k4 * 4) * 4;
+  int b_off0[B_ITERS];
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
+  for (int i = 0; i < B_ITERS; ++i) b_off0[i] = ((b_mr + (NTHREADS / CPRB) * i) * g.ld_dy + n0 + b_n4 * 4) * 4;
+  const int dy_tile_bytes = BK * g.ld_dy * 4;
+  struct Entries {
+    int2 e[A_ITERS];
+  };
+  Entries ent0, ent1;
+
+  constexpr int kLoadOps = A_ITERS + B_ITERS, kStoreOps = A_ITERS + B_ITERS;
+  auto entry_op = [&](int i, int mt, Entries& en) {
+    const int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
+    en.e[i] = buf_load2i(rtab, ((mt < mt_end) & (m < g.M)) ? (unsigned)m * 8u : kOOB);
+  };
+  auto load_op = [&](int idx, int mt, const Entries& en) {
+    if (idx < A_ITERS) {
+      const int i = idx;
       const int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
-      const int img = div_magic(m, g.magic_ohow);
-      const int rem = m - img * g.OHOW;
-      const int oh = div_magic(rem, g.magic_ow);
-      const int ow = rem - oh * g.OW;
-      const int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
-      const bool ok = (m < g.M) & a_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-      ra[i] = buf_load4(rx, ok ? (((unsigned)(img * g.H + ih) * (unsigned)g.W + (unsigned)iw) * (unsigned)g.C + (unsigned)(cbase + a_k4 * 4)) * 4u : kOOB);
-    }
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
+      const int2 e = en.e[i];
+      const int ih = ((e.y << 16) >> 16) + kh, iw = (e.y >> 16) + kw;
+      const bool ok = (mt < mt_end) & (m < g.M) & a_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+      ra[i] = buf_load4(rx, ok ? (unsigned)(e.x + tap_off) : kOOB);
+    } else {
+      const int i = idx - A_ITERS;
       const int m = mt * BK + b_mr + (NTHREADS / CPRB) * i;
-      const bool ok = (m < g.M) & b_nv;
-      rb[i] = buf_load4(rdy, ok ? ((unsigned)m * (unsigned)g.ld_dy + (unsigned)(n0 + b_n4 * 4)) * 4u : kOOB);
+      const bool ok = (mt < mt_end) & (m < g.M) & b_nv;
+      rb[i] = buf_load4(rdy, ok ? (unsigned)(b_off0[i] + mt * dy_tile_bytes) : kOOB);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_op = [&](int idx, int buf) {
     float* sA = sA0 + buf * BK * PA;
     float* sB = sB0 + buf * BK * PB;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i)
+    if (idx < A_ITERS) {
+      const int i = idx;
       *reinterpret_cast<float4*>(sA + (a_mr + (NTHREADS / CPRA) * i) * PA + a_k4 * 4) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
+    } else {
+      const int i = idx - A_ITERS;
       float4 v = rb[i];
       v.x *= gs.x; v.y *= gs.y; v.z *= gs.z; v.w *= gs.w;
       *reinterpret_cast<float4*>(sB + (b_mr + (NTHREADS / CPRB) * i) * PB + b_n4 * 4) = v;
-      if (do_bias) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }   // rows past M / columns past N loaded as 0
+      // rows past M / columns past N / tiles past the end were loaded as 0
+      csum.x += do_bias ? v.x : 0.f; csum.y += do_bias ? v.y : 0.f; csum.z += do_bias ? v.z : 0.f; csum.w += do_bias ? v.w : 0.f;
     }
   };
 
@@ -706,18 +729,43 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
         for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
 
   if (mt_begin < mt_end) {
-    load_tile(mt_begin);
-    store_tile(0);
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) entry_op(i, mt_begin, ent0);
+#pragma unroll
+    for (int op = 0; op < kLoadOps; ++op) load_op(op, mt_begin, ent0);
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) entry_op(i, mt_begin + 1, ent1);
+#pragma unroll
+    for (int op = 0; op < kStoreOps; ++op) store_op(op, 0);
     __syncthreads();
     const int a_off = hi * PA + wm * (BMK / 2) + l31;
     const int b_off = hi * PB + wn * (BN / 2) + l31;
-    for (int mt = mt_begin; mt < mt_end; ++mt) {
-      const int buf = (mt - mt_begin) & 1;
-      const bool more = mt + 1 < mt_end;
-      if (more) load_tile(mt + 1);
-      mfma_tile<TM, TN, CH>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, accs, NoStaging());
-      if (more) store_tile(buf ^ 1);
+    // Same dealing-out of the staging operations between the MFMA steps as the forward kernel (one basic block per
+    // tile, past-the-end tiles load from kOOB): steps 0.. carry the loads of tile mt+1 (and the table entries of
+    // tile mt+2), the last steps but one its LDS stores -- one register stage, the loads have 7+ MFMA steps to land.
+    constexpr int kSteps = BK / 2;
+    constexpr int kStoreSteps = (kStoreOps < kSteps - 1 - kLoadOps) ? kStoreOps : kSteps - 1 - kLoadOps;
+    constexpr int kStoresPerStep = (kStoreOps + kStoreSteps - 1) / kStoreSteps;
+    constexpr int kFirstStoreStep = kSteps - 1 - kStoreSteps;
+    static_assert(kStoreSteps >= 1, "tile too large for the 16-step staging schedule");
+    auto step = [&](int mt, int buf, Entries& cur, Entries& nxt) {   // cur: entries of tile mt+1, nxt: receives mt+2
+      mfma_tile<TM, TN, CH>(sA0 + buf * BK * PA, sB0 + buf * BK * PB, PA, PB, a_off, b_off, accs, [&](int s) {
+        if (s < kLoadOps) {
+          load_op(s, mt + 1, cur);
+          if (s < A_ITERS) entry_op(s, mt + 2, nxt);
+        } else if (s >= kFirstStoreStep && s < kSteps - 1) {
+#pragma unroll
+          for (int q = 0; q < kStoresPerStep; ++q) {
+            const int op = (s - kFirstStoreStep) * kStoresPerStep + q;
+            if (op < kStoreOps) store_op(op, buf ^ 1);
+          }
+        }
+      });
       __syncthreads();
+    };
+    for (int mt = mt_begin; mt < mt_end; mt += 2) {
+      step(mt, 0, ent1, ent0);
+      if (mt + 1 < mt_end) step(mt + 1, 1, ent0, ent1);
     }
   }
   f32x16(&acc)[TM][TN] = accs[0];
@@ -859,6 +907,31 @@ radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, 
   }
   auto ins = ctx->unit_tables.emplace(key, tb);
   return &ins.first->second;
+}
+
+// Row table of a convolution geometry for the wgrad kernel: entry m = output pixel (image, oh, ow) holds the byte offset
+// of its window origin (image, oh*stride - pad_t, ow*stride - pad_l, channel 0) in x -- negative inside the halo -- and
+// the origin's (ih0, iw0) packed into 16 + 16 bits.  Built on the host at the first use of a geometry, cached on the
+// context (device memory, freed with it).
+const int2* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  const std::array<int, 9> key{d->nb, d->h, d->w_, d->c, d->oh, d->ow, d->stride, d->pad_t, d->pad_l};
+  auto it = ctx->row_tables.find(key);
+  if (it != ctx->row_tables.end()) return (const int2*)it->second;
+  const int M = d->nb * d->oh * d->ow;
+  std::vector<int> host((size_t)M * 2);
+  size_t m = 0;
+  for (int img = 0; img < d->nb; ++img)
+    for (int oh = 0; oh < d->oh; ++oh)
+      for (int ow = 0; ow < d->ow; ++ow, ++m) {
+        const int ih0 = oh * d->stride - d->pad_t, iw0 = ow * d->stride - d->pad_l;
+        host[2 * m] = (int)((((int64_t)img * d->h + ih0) * d->w_ + iw0) * d->c * 4);
+        host[2 * m + 1] = (int)(((unsigned)ih0 & 0xFFFFu) | ((unsigned)iw0 << 16));
+      }
+  void* dev = nullptr;
+  if (hipMalloc(&dev, host.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  ctx->row_tables.emplace(key, dev);
+  return (const int2*)dev;
 }
 
 template <int BMODE, bool SMALLC>
@@ -1029,11 +1102,11 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
   g.M = d->nb * d->oh * d->ow; g.N = d->n; g.K = d->kh * d->kw * d->c;
   g.ld_dy = d->ld_dy; g.ldw = d->ldw;
-  g.OHOW = d->oh * d->ow;
   if (g.M >= (1 << 20)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: M=%d exceeds 2^20", g.M);
   if ((g.N & 3) || (g.ld_dy & 3) || (g.ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: n, ld_dy, ldw must be multiples of 4");
-  g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
-  g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  if (d->h >= 32768 || d->w_ >= 32768) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: input %dx%d exceeds the 16-bit row table", d->h, d->w_);
+  g.rowtab = get_row_table(ctx, d);
+  if (!g.rowtab) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv_wgrad: cannot build the row table");
   {
     const uint64_t xb = (uint64_t)d->nb * d->h * d->w_ * d->c * 4ull, db = (uint64_t)g.M * g.ld_dy * 4ull;
     if (xb >= (1ull << 31) || db >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: tensor larger than 2 GiB");

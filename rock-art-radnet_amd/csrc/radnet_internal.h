@@ -45,6 +45,7 @@ struct radnet_ctx {
   int force_a = 0, force_b = 0, force_splits = 0;      // radnet_force_config (tests): overrides tuned / heuristic choices
   std::map<radnet_shape_key, radnet_tuned> tuned;
   std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
+  std::map<std::array<int, 9>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)
   hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
