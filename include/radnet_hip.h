@@ -57,6 +57,9 @@ int radnet_tune_load(radnet_ctx* ctx, const char* path);
 /* Test hook: force every following conv GEMM launch to use output tile (tile_a x tile_b in {64,128}) and `slices` K
  * slices per tile (negative = same slices with the XCD-aware workgroup order); tile_a = 0 switches it off. */
 int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);
+/* With radnet_force_config active: waves per workgroup of the forward / dgrad kernel (4, or 8 = every K tile halved
+ * between two wave grids and summed through LDS); 0 = default (4). */
+int radnet_force_waves(radnet_ctx* ctx, int waves);
 /* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
  * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
  * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd,1 dgrad,2 wgrad). */

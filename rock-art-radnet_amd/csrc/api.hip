@@ -63,10 +63,10 @@ extern "C" int radnet_tune_save(radnet_ctx* ctx, const char* path) {
   if (!ctx || !path) return RADNET_ERR_ARG;
   FILE* f = fopen(path, "w");
   if (!f) RADNET_FAIL(ctx, RADNET_ERR_ARG, "tune_save: cannot open %s", path);
-  fprintf(f, "# radnet tuned GEMM launch shapes v1: kind m n k c npos stride | tile_a tile_b slices ms\n");
+  fprintf(f, "# radnet tuned GEMM launch shapes v2: kind m n k c npos stride | tile_a tile_b slices ms waves\n");
   for (const auto& kv : ctx->tuned)
-    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %.6f\n", kv.first.kind, kv.first.m, kv.first.n, kv.first.k, kv.first.c, kv.first.npos,
-            kv.first.stride, kv.second.a, kv.second.b, kv.second.splits, (double)kv.second.ms);
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %.6f %d\n", kv.first.kind, kv.first.m, kv.first.n, kv.first.k, kv.first.c, kv.first.npos,
+            kv.first.stride, kv.second.a, kv.second.b, kv.second.splits, (double)kv.second.ms, kv.second.waves);
   fclose(f);
   return RADNET_OK;
 }
@@ -82,7 +82,10 @@ extern "C" int radnet_tune_load(radnet_ctx* ctx, const char* path) {
     radnet_shape_key k{};
     radnet_tuned t{};
     double ms = 0.0;
-    if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %lf", &k.kind, &k.m, &k.n, &k.k, &k.c, &k.npos, &k.stride, &t.a, &t.b, &t.splits, &ms) != 11) continue;
+    int waves = 4;
+    if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %lf %d", &k.kind, &k.m, &k.n, &k.k, &k.c, &k.npos, &k.stride, &t.a, &t.b, &t.splits, &ms,
+               &waves) < 11) continue;
+    t.waves = waves == 8 ? 8 : 4;
     if ((t.a != 64 && t.a != 128) || (t.b != 64 && t.b != 128) || t.splits == 0 || t.splits > 64 || t.splits < -64) continue;
     t.ms = (float)ms;
     ctx->tuned[k] = t;
@@ -99,6 +102,12 @@ extern "C" int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int 
   ctx->force_a = tile_a;
   ctx->force_b = tile_b;
   ctx->force_splits = slices;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_force_waves(radnet_ctx* ctx, int waves) {
+  if (!ctx || (waves != 0 && waves != 4 && waves != 8)) return RADNET_ERR_ARG;
+  ctx->force_waves = waves;
   return RADNET_OK;
 }
 

@@ -178,10 +178,12 @@ __device__ __forceinline__ void mfma_tile(const float* sA, const float* sB, int 
 // reads row 8q + 4h + j.  kRowPitch = 36 words: a ds_read_b128 lane group (16 lanes, rows {0-3,12-15,20-27} + 4g)
 // lands on 16 distinct 4-bank sets, and the 8-lane groups of the ds_write_b128 cover 32 consecutive words.
 constexpr int kRowPitch = BK + 4;
-template <int TM, int TN, int CH, bool B_ROWMAJOR, typename Staging>
+// KSTEPS = 16: the wave multiplies the whole 32-deep tile; KSTEPS = 8: half of it (8-wave workgroups: waves 4-7 take
+// k = 16..31, the caller shifts a_off / b_off accordingly and sums the two halves after the K loop).
+template <int TM, int TN, int CH, bool B_ROWMAJOR, int KSTEPS, typename Staging>
 __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB, int pitchB, int a_off, int b_off,
                                                f32x16 (&acc)[CH][TM][TN], Staging staging) {
-  constexpr int kSteps = BK / 2;
+  constexpr int kSteps = KSTEPS;
   float4 af[2][TM], bq[2][TN];
   float bf[3][TN];
 #pragma unroll
@@ -198,7 +200,7 @@ __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB,
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
     const int q = s >> 2, c = s & 3;
-    const bool group_reads = c == 1 && q + 1 < 4;     // next group's 16-byte fragments, three steps ahead of their first use
+    const bool group_reads = c == 1 && q + 1 < kSteps / 4;   // next group's 16-byte fragments, three steps ahead of their first use
     const bool step_reads = !B_ROWMAJOR && s + 2 < kSteps;
     if (group_reads) {
 #pragma unroll
@@ -233,12 +235,19 @@ __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB,
 // BMODE 0: B is [K][ldw] row-major (forward).  BMODE 1: B element (k=(pos,co), n=ci) lives at
 //          w[((flip(pos)*cin_fwd + ci) * ldw) + co]  (dgrad: same weight buffer, read transposed).
 // SMALLC : C == 4 (stem with the image padded to 4 channels): one 4-float chunk per kernel position.
-template <int BM, int BN, int BMODE, bool SMALLC>
-__global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
+// WAVES  : 4 = the 2x2 wave grid multiplies whole K tiles; 8 = two such grids share the tile, waves 4-7 taking the
+//          second half of every 32-deep K tile (split-K INSIDE the workgroup: same LDS tile, half the staging work per
+//          thread, twice the waves per SIMD for the same number of workgroups -- a wave cannot hide its own staging
+//          instructions under its own MFMAs, another wave's can).  The halves are summed through LDS after the loop.
+template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WAVES;
   constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave in each direction
   constexpr int PB = BN + 4;                    // forward weights: k-major [BK][PB]
-  constexpr int A_ITERS = BM / 32;              // float4 chunks per thread (A)
-  constexpr int B_ITERS = BN / 32;
+  constexpr int A_ITERS = BM * 8 / NT;          // float4 chunks per thread (A)
+  constexpr int B_ITERS = BN * 8 / NT;
+  constexpr int kRowStep = NT / 8;              // rows between a thread's consecutive chunks
+  constexpr int kStepsW = (BK / 2) / (WAVES / 4);   // MFMA steps of one wave per K tile
   // one LDS buffer: A row-major [BM][kRowPitch]; B k-major [BK][PB] (forward) or row-major [BN][kRowPitch] (dgrad)
   constexpr int kBufA = BM * kRowPitch;
   constexpr int kBufB = (BMODE == 0) ? BK * PB : BN * kRowPitch;
@@ -254,7 +263,8 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int khalf = wave >> 2;                  // 0 for 4-wave workgroups
   // Work assignment.  Plain launch: one workgroup per output tile.  Unit-table launch (g.units != null): the host
   // cut the linearised (tile, k-tile) iteration space into near-equal chunks so every CU gets the same amount of
   // MFMA work whatever the tile count (stream-K style); a unit is (tile, k range, partial slot or -1).
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
   const int a_cbytes = (SMALLC ? 4 : g.C) * 4;
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
-    const int m = m0 + (tid >> 3) + 32 * i;
+    const int m = m0 + (tid >> 3) + kRowStep * i;
     const int mc = m < g.M ? m : 0;
     const int img = div_magic(mc, g.magic_ohow);
     const int rem = mc - img * g.OHOW;
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     constexpr int CPR = BN / 4;
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      const int c = tid + NTHREADS * i;
+      const int c = tid + NT * i;
       const int kr = c / CPR, n = n0 + (c - kr * CPR) * 4;
       b_base[i] = (kr * g.ldw + n) * 4;
       b_nvalid[i] = n < g.N;
@@ -381,13 +391,13 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     } else if (BMODE == 0) {
       constexpr int CPR = BN / 4;            // float4 chunks per k row
       const int i = idx - A_ITERS;
-      const int c = tid + NTHREADS * i;
+      const int c = tid + NT * i;
       const int kr = c / CPR;
       const bool ok = t_live & (t_kt * BK + kr < g.K) & b_nvalid[i];   // N is a multiple of 4 (launcher checks)
       st.b[i] = buf_load4(rw, ok ? (unsigned)(b_base[i] + t_kt * b_tile_bytes) : kOOB);
     } else {
       const int i = idx - A_ITERS;
-      const int n = n0 + (tid >> 3) + 32 * i;   // forward input channel
+      const int n = n0 + (tid >> 3) + kRowStep * i;   // forward input channel
       const bool ok = t_kv & (n < g.N);
       st.b[i] = buf_load4(rw, ok ? (((unsigned)t_fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)t_ci) * 4u : kOOB);
     }
@@ -407,16 +417,16 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
         v.z *= has_in_scale ? st.s.z : 1.f;
         v.w *= has_in_scale ? st.s.w : 1.f;
       }
-      *reinterpret_cast<float4*>(sA + ((tid >> 3) + 32 * i) * kRowPitch + a_kc * 4) = v;
+      *reinterpret_cast<float4*>(sA + ((tid >> 3) + kRowStep * i) * kRowPitch + a_kc * 4) = v;
     } else if (BMODE == 0) {
       constexpr int CPR = BN / 4;
       const int i = op - A_ITERS;
-      const int cc = tid + NTHREADS * i;
+      const int cc = tid + NT * i;
       const int kr = cc / CPR, n4 = cc - kr * CPR;
       *reinterpret_cast<float4*>(sB + kr * PB + n4 * 4) = st.b[i];
     } else {
       const int i = op - A_ITERS;
-      *reinterpret_cast<float4*>(sB + ((tid >> 3) + 32 * i) * kRowPitch + a_kc * 4) = st.b[i];
+      *reinterpret_cast<float4*>(sB + ((tid >> 3) + kRowStep * i) * kRowPitch + a_kc * 4) = st.b[i];
     }
   };
 
@@ -446,18 +456,19 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     t_first = __builtin_amdgcn_s_memtime();
 #endif
     // fragment offsets (see mfma_tile_rows): row-major operands start at (row, k = 4*hi), the k-major one at row 4*hi
-    const int a_off = (wm * (BM / 2) + l31) * kRowPitch + 4 * hi;
-    const int b_off = (BMODE == 0) ? 4 * hi * PB + wn * (BN / 2) + l31 : (wn * (BN / 2) + l31) * kRowPitch + 4 * hi;
+    // (8-wave workgroups: waves 4-7 start at k = 16 of the tile)
+    const int a_off = (wm * (BM / 2) + l31) * kRowPitch + 4 * hi + 16 * khalf;
+    const int b_off = (BMODE == 0) ? (4 * hi + 16 * khalf) * PB + wn * (BN / 2) + l31 : (wn * (BN / 2) + l31) * kRowPitch + 4 * hi + 16 * khalf;
     // invariant at the top of step(kt, buf): LDS buffer `buf` holds tile kt; stage `nxt` holds tile kt+1 (in flight or
     // landed); stage `cur` is free.  MFMA steps 0 .. kLoadOps-1 each carry one global load of tile kt+2, the steps
     // after them (all but the last, which has no MFMA behind it to hide under) the LDS stores of tile kt+1.
-    constexpr int kSteps = BK / 2;
+    constexpr int kSteps = kStepsW;
     constexpr int kStoreSteps = kSteps - 1 - kLoadOps;
     constexpr int kStoresPerStep = (kStoreOps + kStoreSteps - 1) / kStoreSteps;
-    static_assert(kStoreSteps >= 1, "tile too large for the 16-step staging schedule");
+    static_assert(kStoreSteps >= 1, "tile too large for the staging schedule");
     auto step = [&](int kt, int buf, Stage& cur, Stage& nxt) {
       tile_begin(kt + 2, kt + 2 < kt_end, cur);
-      mfma_tile_rows<TM, TN, CH, BMODE != 0>(sA0 + buf * kBufA, sB0 + buf * kBufB, PB, a_off, b_off, accs, [&](int s) {
+      mfma_tile_rows<TM, TN, CH, BMODE != 0, kStepsW>(sA0 + buf * kBufA, sB0 + buf * kBufB, PB, a_off, b_off, accs, [&](int s) {
         if (s < kLoadOps) {
 #ifndef RADNET_DIAG_SKIP_LOADS
           load_op(s, cur);
@@ -488,6 +499,32 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] += accs[c][i][j];
+  // 8-wave workgroups: waves 4-7 hold the sums over the second half of every K tile; they hand them to waves 0-3
+  // through the (now free) staging array and take no further part in the output -- every global access below is
+  // predicated on live_out (offset kOOB otherwise), the barriers are reached by all eight waves.
+  bool live_out = true;
+  if (WAVES == 8) {
+    float* red = lds + ((wave & 3) * TM * TN * 16) * 64 + lane;
+    if (khalf == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (khalf == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64];
+    }
+    __syncthreads();
+    live_out = khalf == 0;
+  }
 #ifdef RADNET_DIAG_STAMPS
   t_loop = __builtin_amdgcn_s_memtime();
   // stamps go to a buffer of their own; nothing the kernel outputs is computed from them.  The epilogue stamp is
@@ -516,7 +553,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
     // before the barrier, one lane takes the relaxed agent-scope ticket, and EVERY slab load of the reducer is an
     // sc1 load -- no release / acquire cache maintenance (the plain-store + fence form cost 5-12 us per workgroup
     // here: each release writes back the XCD's whole L2).  Correct for any placement of the slices on XCDs / CUs.
-    const unsigned lane_off = (unsigned)((wm * (BM / 2) + 4 * hi) * BN + wn * (BN / 2) + l31) * 4u;
+    const unsigned lane_off = live_out ? (unsigned)((wm * (BM / 2) + 4 * hi) * BN + wn * (BN / 2) + l31) * 4u : kOOB;
     const __amdgpu_buffer_rsrc_t rslab = make_rsrc(g.partial + (size_t)slot * (BM * BN), BM * BN * 4u);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -583,7 +620,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        const bool ok = nv & (m < g.M);
+        const bool ok = live_out & nv & (m < g.M);
         ad[r] = buf_load1(radd, ok ? ((unsigned)m * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB);
         mk[r] = 1.f;
         if (has_mask) mk[r] = buf_load1(rmask, ok ? ((unsigned)m * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB);
@@ -591,7 +628,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        const bool ok = nv & (m < g.M);
+        const bool ok = live_out & nv & (m < g.M);
         float v = acc[i][j][r] * sc + sh + ad[r];
         if (!(mk[r] > 0.f)) v = 0.f;
         if (g.act == 1) v = fmaxf(v, 0.f);
@@ -819,6 +856,7 @@ constexpr int kNumCU = 256;
 
 struct TileChoice {
   int bm, bn, splits;
+  int waves = 4;         // waves per workgroup (4, or 8 = K tile halved between two wave grids)
 };
 
 // Pick the output tile and split-K factor.  Cost model (CU-time in MAC units, 128 MAC/clk/CU):
@@ -934,16 +972,22 @@ const int2* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
   return (const int2*)dev;
 }
 
+template <int BMODE, bool SMALLC, int WAVES>
+void launch_igemm_w(hipStream_t st, const GemmArgs& g, const TileChoice& tc, dim3 grid) {
+  dim3 block(64 * WAVES);
+  // (capping workgroups per CU with extra dynamic LDS was measured: 7-25 % slower on every layer -- co-residency wins)
+  if (tc.bm == 128 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
+  else if (tc.bm == 128 && tc.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
+  else if (tc.bm == 64 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<64, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
+}
+
 template <int BMODE, bool SMALLC>
 void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n_units) {
-  dim3 block(NTHREADS);
   dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), 1);
   if (g.units != nullptr) grid = dim3(n_units, 1, 1);
-  // (capping workgroups per CU with extra dynamic LDS was measured: 7-25 % slower on every layer -- co-residency wins)
-  if (tc.bm == 128 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, BMODE, SMALLC>), grid, block, 0, st, g);
-  else if (tc.bm == 128 && tc.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, BMODE, SMALLC>), grid, block, 0, st, g);
-  else if (tc.bm == 64 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<64, 128, BMODE, SMALLC>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, BMODE, SMALLC>), grid, block, 0, st, g);
+  if (tc.waves == 8) launch_igemm_w<BMODE, SMALLC, 8>(st, g, tc, grid);
+  else launch_igemm_w<BMODE, SMALLC, 4>(st, g, tc, grid);
 }
 
 int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
@@ -1007,10 +1051,10 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   TileChoice tc{64, 64, 1};
   auto it = ctx->tuned.find(key);
   if (ctx->force_a > 0) {                      // radnet_force_config: tests sweep every tile / slice / order variant
-    tc = TileChoice{ctx->force_a, ctx->force_b, ctx->force_splits};
+    tc = TileChoice{ctx->force_a, ctx->force_b, ctx->force_splits, ctx->force_waves == 8 ? 8 : 4};
     if (tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
   } else if (it != ctx->tuned.end()) {
-    tc = TileChoice{it->second.a, it->second.b, it->second.splits};
+    tc = TileChoice{it->second.a, it->second.b, it->second.splits, it->second.waves == 8 ? 8 : 4};
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int chunks[] = {1, 2, 3, 4, 5, 6, 8, 12};                 // K slices per tile
@@ -1022,19 +1066,21 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
         if (s > 1 && (ctx->ws == nullptr || nk / s < 4)) continue;              // slices shorter than 4 k-tiles
         for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
           if (sign < 0 && tiles * s < 16) continue;
-          TileChoice t{cand[c][0], cand[c][1], sign * s};
-          float ms = 0.f;
-          int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
-          if (rc == RADNET_ERR_UNSUPPORTED) continue;
-          if (rc != RADNET_OK) return rc;
-          if (ms < best) { best = ms; tc = t; }
+          for (int waves = 4; waves <= 8; waves += 4) {                         // 8 = K tile halved between two wave grids
+            TileChoice t{cand[c][0], cand[c][1], sign * s, waves};
+            float ms = 0.f;
+            int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
+            if (rc == RADNET_ERR_UNSUPPORTED) continue;
+            if (rc != RADNET_OK) return rc;
+            if (ms < best) { best = ms; tc = t; }
+          }
         }
       }
     }
-    ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best};
+    ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best, tc.waves};
     if (getenv("RADNET_TUNE_LOG"))
-      fprintf(stderr, "[radnet tune] %s M=%d N=%d K=%d C=%d -> tile %dx%d chunks %d : %.1f us (%.1f TFLOP/s)\n", cls == 1 ? "dgrad" : "fwd", g.M,
-              g.N, g.K, g.C, tc.bm, tc.bn, tc.splits, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
+      fprintf(stderr, "[radnet tune] %s M=%d N=%d K=%d C=%d -> tile %dx%d chunks %d waves %d : %.1f us (%.1f TFLOP/s)\n", cls == 1 ? "dgrad" : "fwd",
+              g.M, g.N, g.K, g.C, tc.bm, tc.bn, tc.splits, tc.waves, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
   } else {
     tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
   }
@@ -1153,7 +1199,7 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
         }
       }
     }
-    ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best};
+    ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best, 4};
     if (getenv("RADNET_TUNE_LOG"))
       fprintf(stderr, "radnet tune: wgrad M=%d N=%d K=%d C=%d -> tile %dx%d slices %d : %.1f us (%.1f TFLOP/s)\n", g.M, g.N, g.K, g.C,
               bmk, bn, splits, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));

@@ -31,6 +31,7 @@ struct radnet_shape_key {
 struct radnet_tuned {
   int a, b, splits;
   float ms;
+  int waves = 4;
 };
 
 // Device-resident work-unit / fix-up tables of a K-split GEMM launch (conv_mfma.hip: get_unit_table).
@@ -42,7 +43,7 @@ struct radnet_unit_table {
 
 struct radnet_ctx {
   int autotune = 0;
-  int force_a = 0, force_b = 0, force_splits = 0;      // radnet_force_config (tests): overrides tuned / heuristic choices
+  int force_a = 0, force_b = 0, force_splits = 0, force_waves = 0;      // radnet_force_config (tests): overrides tuned / heuristic choices
   std::map<radnet_shape_key, radnet_tuned> tuned;
   std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
   std::map<std::array<int, 9>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)

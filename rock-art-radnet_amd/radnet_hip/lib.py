@@ -73,6 +73,7 @@ def load_library():
         "radnet_tune_save": (C.c_int, [vp, C.c_char_p]),
         "radnet_tune_load": (C.c_int, [vp, C.c_char_p]),
         "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "radnet_force_waves": (C.c_int, [vp, C.c_int]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
         "radnet_timing_reset": (C.c_int, [vp]),

@@ -1,5 +1,5 @@
-"""Every launch variant of the conv GEMM kernels (output tile x K slices x workgroup order), forced one by one through
-radnet_force_config, against the oracle.  The autotuner may pick any of them at run time, so each must be correct on
+"""Every launch variant of the conv GEMM kernels (output tile x K slices x workgroup order x waves per workgroup), forced
+one by one through radnet_force_config / radnet_force_waves, against the oracle.  The autotuner may pick any of them at run time, so each must be correct on
 its own -- including ragged M / N edges, stride 2, 3x3 halos, odd and even K-tile counts per slice."""
 import ctypes as C
 import itertools
@@ -33,7 +33,7 @@ FWD_SHAPES = [
     (1, 21, 30, 64, 256, 1, 1, 0),           # short K (2 K tiles)
     (1, 17, 19, 224, 64, 1, 1, 0),           # 7 K tiles (odd): exercises the two-stage pipeline tail
 ]
-CONFIGS = [(bm, bn, s) for bm, bn in itertools.product((64, 128), (64, 128)) for s in (1, 2, 3, 5, -1, -4)]
+CONFIGS = [(bm, bn, s, wv) for bm, bn in itertools.product((64, 128), (64, 128)) for s in (1, 2, 3, 5, -1, -4) for wv in (4, 8)]
 
 
 @pytest.mark.parametrize("shape", FWD_SHAPES)
@@ -57,21 +57,23 @@ def test_fwd_and_dgrad_every_config(ctx, shape):
         dx_ref = dx_ref * (x > 0)
         dyd = dev(dy)
         nk_d = (k * k * cout + 31) // 32
-    for bm, bn, s in CONFIGS:
+    for bm, bn, s, wv in CONFIGS:
         if abs(s) > nk:
             continue
         ctx.check(ctx.lib.radnet_force_config(ctx.h, bm, bn, s), "force")
+        ctx.check(ctx.lib.radnet_force_waves(ctx.h, wv), "force waves")
         y = torch.full((nb, oh, ow, cout), float("nan"), dtype=torch.float32, device="cuda")
         d = conv_desc(L, xd, wd, y, nb, h, w, cin, oh, ow, k, stride, pad, cout, cout, sd, bd, None, 1)
-        ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd %s" % ((bm, bn, s),))
+        ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd %s" % ((bm, bn, s, wv),))
         close(y.cpu().numpy(), ref)
         if do_dgrad and abs(s) <= nk_d:
             dx = torch.full((nb, h, w, cin), float("nan"), device="cuda")
             d.dy, d.ld_dy, d.gscale = dyd.data_ptr(), cout, sd.data_ptr()
             d.dx, d.ld_dx, d.dx_add, d.dx_mask, d.ld_dx_mask = dx.data_ptr(), cin, None, xd.data_ptr(), cin
-            ctx.check(ctx.lib.radnet_conv_dgrad(ctx.h, C.byref(d)), "conv_dgrad %s" % ((bm, bn, s),))
+            ctx.check(ctx.lib.radnet_conv_dgrad(ctx.h, C.byref(d)), "conv_dgrad %s" % ((bm, bn, s, wv),))
             close(dx.cpu().numpy(), dx_ref)
     ctx.lib.radnet_force_config(ctx.h, 0, 0, 0)
+    ctx.lib.radnet_force_waves(ctx.h, 0)
 
 
 @pytest.mark.parametrize("shape", [(20, 7, 7, 512, 512, 3, 1, 1), (20, 14, 14, 1024, 512, 1, 2, 0), (1, 19, 23, 128, 96, 3, 1, 1)])

@@ -36,6 +36,9 @@ SHAPES = [
 ]
 
 
+WAVES = int(os.environ.get("RADNET_PROBE_WAVES", "4"))      # waves per workgroup of the probed launches (4 or 8)
+
+
 def main():
     lib = L.load_library()
     lib.radnet_diag_set_stamps.restype = C.c_int
@@ -60,6 +63,7 @@ def main():
         d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.n = k, k, stride, pad, pad, cout
         d.ldw, d.ldy, d.ld_add, d.act, d.act_cols = cout, cout, cout, 1, 0
         ctx.check(lib.radnet_force_config(ctx.h, bm, bn, s), "force")
+        ctx.check(lib.radnet_force_waves(ctx.h, WAVES), "force waves")
         ctx.check(lib.radnet_diag_set_stamps(ctx.h, None), "stamps off")
         for _ in range(300):
             ctx.check(lib.radnet_conv_fwd(ctx.h, C.byref(d)), "fwd")
@@ -95,7 +99,7 @@ def main():
         M, K = nb * oh * ow, k * k * cin
         fl = 2.0 * M * cout * K
         q = lambda a: "%.1f/%.1f/%.1f" % (np.percentile(a, 10), np.median(a), np.percentile(a, 90))  # noqa: E731
-        print("%s  [%dx%d s=%d]  M=%d N=%d K=%d" % (name, bm, bn, s, M, cout, K))
+        print("%s  [%dx%d s=%d waves=%d]  M=%d N=%d K=%d" % (name, bm, bn, s, WAVES, M, cout, K))
         print("   wall %.1f us/launch (%.1f TF/s); %d workgroups on %d CUs (per CU %d..%d); in-kernel clock %.0f MHz" % (
             wall, fl / wall / 1e6, n, ncu, per_cu.min(), per_cu.max(), clk))
         print("   span first start -> last end %.1f us; starts p10/50/90 %s max %.1f; ends p10/50/90 %s" % (
