@@ -98,6 +98,15 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 __device__ __forceinline__ float buf_load1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 16));
 }
+__device__ __forceinline__ float4 buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store4_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 f = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, (int)off, 0, 16);
+}
 __device__ __forceinline__ void buf_store1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 16);
 }
@@ -553,15 +562,18 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     // before the barrier, one lane takes the relaxed agent-scope ticket, and EVERY slab load of the reducer is an
     // sc1 load -- no release / acquire cache maintenance (the plain-store + fence form cost 5-12 us per workgroup
     // here: each release writes back the XCD's whole L2).  Correct for any placement of the slices on XCDs / CUs.
-    const unsigned lane_off = live_out ? (unsigned)((wm * (BM / 2) + 4 * hi) * BN + wn * (BN / 2) + l31) * 4u : kOOB;
+    // Slab layout is private to this kernel: each lane keeps the 16 registers of a 32x32 accumulator contiguous
+    // (64 bytes), so a slab moves with four 16-byte accesses per accumulator instead of sixteen 4-byte ones.
+    const unsigned lane_off = live_out ? (unsigned)(((wave & 3) * TM * TN * 64 + lane) * 16) * 4u : kOOB;
     const __amdgpu_buffer_rsrc_t rslab = make_rsrc(g.partial + (size_t)slot * (BM * BN), BM * BN * 4u);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          buf_store1_sc1(rslab, lane_off + (unsigned)((i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32) * 4u, acc[i][j][r]);
+        for (int q = 0; q < 4; ++q)
+          buf_store4_sc1(rslab, lane_off + (unsigned)(((i * TN + j) * 64 * 16 + q * 4) * 4),
+                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     volatile int* flag = reinterpret_cast<volatile int*>(lds);      // the staging array is free after the K loop
@@ -585,15 +597,29 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int s = 0; s < n_slices; ++s) {
-      const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g.partial + (size_t)(slot0 + s) * (BM * BN), BM * BN * 4u);
+    // slices are ADDED in slot order (deterministic), but their loads are issued kGroup slices at a time: one memory
+    // round trip per group instead of one per slice (a slice past the end reads from kOOB, i.e. zeros)
+    constexpr int kGroup = (TM * TN == 1) ? 4 : (TM * TN == 2 ? 2 : 1);
+    for (int s0 = 0; s0 < n_slices; s0 += kGroup) {
+      float4 v[kGroup][TM * TN * 4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int u = 0; u < kGroup; ++u) {
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g.partial + (size_t)(slot0 + s0 + u) * (BM * BN), BM * BN * 4u);
+        const unsigned off = (s0 + u < n_slices) ? lane_off : kOOB;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int t = 0; t < TM * TN * 4; ++t) v[u][t] = buf_load4_sc1(rsrc, off + (unsigned)(((t >> 2) * 64 * 16 + (t & 3) * 4) * 4));
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += buf_load1_sc1(rsrc, lane_off + (unsigned)((i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32) * 4u);
+      for (int u = 0; u < kGroup; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 w = v[u][(i * TN + j) * 4 + q];
+              acc[i][j][4 * q] += w.x; acc[i][j][4 * q + 1] += w.y; acc[i][j][4 * q + 2] += w.z; acc[i][j][4 * q + 3] += w.w;
+            }
     }
   }
   // Branch-free like the operand loads: rows past M / columns past N get the offset kOOB, which the hardware answers
