@@ -114,14 +114,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ts.step(batch)
+        ts.step(batch, next_batch=batch)
     barrier()
     if args.tune_cache is not None and not have_cache and rank == 0:
         eng.save_tuning(args.tune_cache)
     skipped0 = ts.skipped_head_steps
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.step(batch)
+    for k in range(args.steps):
+        # the input pipeline knows the next batch: its label / base-forward phases are enqueued across the host sync
+        ts.step(batch, next_batch=batch if k + 1 < args.steps else None)
     ts.flush()                       # multi-GPU: the last step's deferred head update belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0

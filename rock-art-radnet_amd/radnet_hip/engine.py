@@ -719,6 +719,10 @@ class FasterRCNNEngine:
     def roi_targets(self, R_dev, n_dev, gt, width, height, rw, rh, n_max=300):
         """rpn.calc_iou on device for the first min(*n_dev, n_max) proposals; one pinned D2H brings back the per-RoI
         class code (-1 = dropped).  Returns (plan, cls host int32 [n], n)."""
+        return self.roi_targets_finish(self.roi_targets_launch(R_dev, n_dev, gt, width, height, rw, rh, n_max))
+
+    def roi_targets_launch(self, R_dev, n_dev, gt, width, height, rw, rh, n_max=300):
+        """Device half of roi_targets + asynchronous copy of the class codes to pinned memory."""
         dev = self.dev
         key = ("rtgt",)
         if key not in self._plans:
@@ -736,7 +740,15 @@ class FasterRCNNEngine:
         self.ctx.check(rc, "radnet_roi_targets")
         P["h_cls"][:n_max].copy_(P["cls"][:n_max], non_blocking=True)
         P["h_n"].copy_(n_dev, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if "event" not in P:
+            P["event"] = torch.cuda.Event()
+        P["event"].record()
+        return P
+
+    @staticmethod
+    def roi_targets_finish(P):
+        """Waits for the class codes only (an event after their copy), not for whatever was enqueued behind them."""
+        P["event"].synchronize()
         n = int(P["h_n"][0])
         return P, P["h_cls"].numpy()[:max(n, 0)], n
 

@@ -61,6 +61,8 @@ class TrainStep:
         self.group = dist_group
         self.defer_head_update = (world_size > 1) if defer_head_update is None else bool(defer_head_update)
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
+        self._pre = None                 # phases A/B of the next batch, enqueued ahead (step(next_batch=...))
+        self._parity = 0                 # buffer set the next _launch_ab uses
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
@@ -96,9 +98,32 @@ class TrainStep:
             s["_gt_dev"] = self.eng.upload_gt(boxes, isbg, cls)
         return s["_gt_dev"]
 
-    def step(self, batch):
+    def _launch_ab(self, batch, parity):
+        """Device half of phase A (anchor labelling + async copy of the label maps) and phase B (upload, base forward,
+        RPN forward) of every image of `batch`, into the buffer set `parity`.  Touches frozen base weights and RPN
+        weights only."""
+        eng = self.eng
+        nloc = len(batch)
+        tp, plans, rps = [], [], []
+        for i, s in enumerate(batch):
+            H, W = s["img"].shape[:2]
+            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=parity * nloc + i))
+        for i, s in enumerate(batch):
+            bp = eng.upload_image(s["img"], slot=parity * nloc + i)
+            eng.base_forward(bp)
+            plans.append(bp)
+            rps.append(eng.rpn_forward(bp))
+        return dict(batch=batch, tp=tp, plans=plans, rps=rps, parity=parity)
+
+    def step(self, batch, next_batch=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
-        width, height: source-frame size the boxes refer to}.  Losses of the step: self.losses()."""
+        width, height: source-frame size the boxes refer to}.  Losses of the step: self.losses().
+
+        next_batch (optional, what a prefetching data loader knows): its phases A/B are ENQUEUED while this step waits
+        for the RoI class codes -- the one point where the host must drain the GPU (sample selection runs on NumPy's
+        RNG).  They read only the frozen base and the RPN weights, which nothing after this step's Adam #1 changes, so
+        the arithmetic and the order of RNG draws are exactly those of back-to-back steps; the GPU just never idles
+        while the host selects samples and builds the head batch.  The next call must pass that same object."""
         eng = self.eng
         C = eng.C
         nloc = len(batch)
@@ -111,17 +136,14 @@ class TrainStep:
                 marks.append((label, time.perf_counter()))
 
         mark("start")
-        # ---- phase A (device half) + phase B, all asynchronous
-        tp, plans, rps = [], [], []
-        for i, s in enumerate(batch):
-            H, W = s["img"].shape[:2]
-            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=i))
-        mark("A: anchor kernels enqueued")
-        for i, s in enumerate(batch):
-            bp = eng.upload_image(s["img"], slot=i)
-            eng.base_forward(bp)
-            plans.append(bp)
-            rps.append(eng.rpn_forward(bp))
+        # ---- phase A (device half) + phase B, all asynchronous -- unless the previous step already enqueued them
+        if self._pre is not None and self._pre["batch"] is batch:
+            st = self._pre
+        else:
+            st = self._launch_ab(batch, self._parity)
+        self._pre = None
+        self._parity = st["parity"] ^ 1
+        tp, plans, rps = st["tp"], st["plans"], st["rps"]
         mark("B: upload + base + rpn forward enqueued")
         # ---- phase A (host half, overlapped with B) + phase C
         # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
@@ -141,9 +163,12 @@ class TrainStep:
             eng._run(rp["fwd"])
             R, Rn = eng.proposals(rp, overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
+            P = eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)
+            if next_batch is not None and i == nloc - 1:
+                self._pre = self._launch_ab(next_batch, self._parity)      # keeps the GPU busy across the sync below
             mark("D: rpn re-predict + proposals + roi targets enqueued")
-            P, cls, n = eng.roi_targets(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)      # one sync
-            mark("D: roi classes on host (GPU drained)")
+            P, cls, n = eng.roi_targets_finish(P)                             # the step's one host sync in this phase
+            mark("D: roi classes on host")
             kept = np.nonzero(cls >= 0)[0]
             if n <= 0 or len(kept) == 0:                           # calc_iou -> None: the reference skips the head step
                 self.skipped_head_steps += 1

@@ -48,8 +48,7 @@ class FakeEngine:
         return dict(g=len(boxes))
 
     def anchor_targets_launch(self, gt, width, height, W, H, slot=0):
-        if slot == 0:
-            self.k += 1
+        self.k += 1            # one image per step here (slot alternates between the two buffer sets)
         return dict(slot=slot)
 
     def upload_image(self, img, slot=0):
@@ -86,8 +85,12 @@ class FakeEngine:
     def proposals(self, rp, overlap_thresh=0.7, max_boxes=300):
         return None, None
 
-    def roi_targets(self, R, Rn, gt, width, height, rw, rh):
-        return dict(), np.array([0, 1, 0, 1, 1], dtype=np.int32), 5
+    def roi_targets_launch(self, R, Rn, gt, width, height, rw, rh):
+        return dict()
+
+    @staticmethod
+    def roi_targets_finish(P):
+        return P, np.array([0, 1, 0, 1, 1], dtype=np.int32), 5
 
     def _plan_head(self, R, fh, fw, F):
         return dict(bwd=[])

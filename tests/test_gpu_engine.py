@@ -248,3 +248,48 @@ def test_cfg4_two_images_per_step_vs_oracle():
             big = np.abs(d_ref) > 0.9 * 5e-5                               # first Adam step: |delta| ~ lr where the gradient is not tiny
             assert big.sum() > 0
             assert np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
+
+
+def test_prefetched_next_batch_equals_back_to_back_steps():
+    """TrainStep.step(batch, next_batch=...) enqueues the next batch's labelling / base / RPN forward across the host
+    sync of the current step.  Same arithmetic, same order of NumPy RNG draws: three steps with the prefetch must equal
+    three back-to-back steps (up to the fp32 atomics of split wgrad launches)."""
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size = 300
+    P = dense.init_params(seed=3)
+    batches = []
+    for i in range(3):
+        meta = synth.synthetic_gt(40 + i, n=6, src_w=1000, src_h=600, smin=60, smax=300)
+        batches.append([dict(img=synth.synthetic_panel(30 + i, 300, 500), bboxes=meta["bboxes"], width=1000, height=600)])
+    results = []
+    tune = None
+    for prefetch in (False, True):
+        eng = FasterRCNNEngine(C)
+        if tune is not None:
+            eng.load_tuning(tune)                     # same launch shapes -> same summation order
+        eng.set_weights(P)
+        np.random.seed(64)
+        ts = TrainStep(eng)
+        losses = []
+        for k, b in enumerate(batches):
+            ts.step(b, next_batch=batches[k + 1] if prefetch and k + 1 < len(batches) else None)
+            losses.append(ts.losses())
+        results.append((losses, eng.get_weights(), np.random.randint(0, 2 ** 31 - 1)))
+        if tune is None:
+            import tempfile
+            tune = tempfile.mktemp(suffix=".txt")
+            eng.save_tuning(tune)
+    (l0, w0, r0), (l1, w1, r1) = results
+    assert r0 == r1                                   # identical consumption of the global NumPy stream
+    for a, b in zip(l0, l1):
+        assert a["n_head"] == b["n_head"] == 1
+        for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+    for name in ("rpn_conv1", "rpn_out_class", "res5a_branch2a", "res5c_branch2c", "dense_class_7"):
+        for k in ("kernel", "bias"):
+            assert np.allclose(w0[name][k], w1[name][k], rtol=0, atol=2e-7), (name, k)
