@@ -340,6 +340,33 @@ def base_forward(P, x, want_cache=False):
     return (y, caches) if want_cache else y
 
 
+def base_backward(P, caches, dF, stages=(3, 4)):
+    """Gradients of the trainable base stages (cont_train.py:120-131: `trainable` from stage 3 on; FixedBatchNormalization
+    never trains) given dL/dF.  `caches` as returned by base_forward(want_cache=True): [conv1, then one entry per
+    residual block in execution order].  Nothing flows below the first trainable stage."""
+    blocks = []
+    i = 1
+    for st, bls, _, _ in RES_STAGES:
+        for _ in bls:
+            blocks.append((st, caches[i]))
+            i += 1
+    grads = {}
+    dy = dF
+    first_needed = min(stages)
+    for st, c in reversed(blocks):
+        if st not in stages:
+            break
+        lowest = st == first_needed and c["first"]              # the block whose input comes from the frozen part
+        dy, gr = res_block_backward(P, c, dy, need_dx=not lowest)
+        grads.update(gr)
+    return grads
+
+
+def s34_trainable():
+    """Conv layers of ResNet50 stages 3 and 4 (the part of the base cont_train.py unfreezes)."""
+    return [s[0] for s in resnet50_conv_specs() if s[0].startswith(("res3", "res4"))]
+
+
 def rpn_forward(P, F):
     """rpn_layer (rpn.py:12-66): returns (cls sigmoid (1,H,W,A), regr (1,H,W,4A), cache)."""
     h = conv2d(F, P["rpn_conv1"]["kernel"], P["rpn_conv1"]["bias"], 1, (1, 1, 1, 1))

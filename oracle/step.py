@@ -66,6 +66,58 @@ class OracleTrainer:
         return [l_rpn[1], l_rpn[2], l_det[1], l_det[2], l_det[3]]
 
 
+class OracleTrainerCont(OracleTrainer):
+    """cont_train.py trainability (SURVEY.md 8d cfg 2, secondary): ResNet50 stages 3-4 train in BOTH models, each model's
+    Adam keeps its own moments for those shared weights (cont_train.py:169-185), lr 2e-5.  Per iteration: RPN loss ->
+    gradients of the RPN convs and (through rpn_conv1) of stages 3-4 -> Adam #1; the base is then re-run (its weights
+    moved) for the re-prediction and the classifier phase; classifier loss -> gradients of the head and (through the
+    RoI crop-resize) of stages 3-4 -> Adam #2."""
+
+    def __init__(self, C, P, lr=2e-5, keras2_bce=True):
+        super().__init__(C, P, lr, keras2_bce)
+        self.shared = dense.s34_trainable()
+        self.opt_rpn = dense.AdamState(P, list(dense.RPN_TRAINABLE) + self.shared, lr)
+        self.opt_head = dense.AdamState(P, dense.head_trainable(self.nc) + self.shared, lr)
+
+    def step(self, sample, detail=None, override_R=None):
+        C, P = self.C, self.P
+        y_cls, y_regr = self.targets(sample)
+        x = dense.preprocess_caffe_bgr(sample["img"])
+        F, caches = dense.base_forward(P, x, want_cache=True)
+        p, r, rc = dense.rpn_forward(P, F)
+        l_cls, dp = dense.rpn_loss_cls(y_cls.astype(np.float32), p, self.A, self.keras2_bce)
+        l_regr, dr = dense.smooth_l1_masked(y_regr.astype(np.float32), r, 4 * self.A)
+        g_rpn, dF = dense.rpn_backward(P, rc, dp, dr, need_dF=True)
+        g_rpn.update(dense.base_backward(P, caches, dF))
+        if detail is not None:
+            detail.update(g_rpn=g_rpn, dF_rpn=dF, F0=F)
+        self.opt_rpn.apply(P, g_rpn)
+        F, caches = dense.base_forward(P, x, want_cache=True)               # stages 3-4 moved: new feature map
+        p, r, _ = dense.rpn_forward(P, F)
+        R = glue.rpn_to_roi(p, r, C, use_regr=True, overlap_thresh=0.7, max_boxes=300)
+        if detail is not None:
+            detail["R_own"] = R
+        if override_R is not None:
+            R = override_R
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in sample["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        gcls = np.array([C.class_mapping[b["class"]] for b in sample["bboxes"]])
+        X2, Y1, Y2, _ = glue.roi_targets(R, gt, gcls, sample["width"], sample["height"], C)
+        if X2 is None:
+            return [l_cls, l_regr, None, None, None]
+        sel, _ = glue.select_samples(Y1, C.n_rois)
+        rois = X2[0, sel].astype(np.float32)
+        pc, pr, hc = dense.head_forward(P, F, rois, self.nc)
+        lc, dpc = dense.class_loss_cls(Y1[:, sel].astype(np.float32), pc)
+        lr_, dpr = dense.smooth_l1_masked(Y2[:, sel].astype(np.float32), pr, 4 * (self.nc - 1))
+        g_head, dpooled = dense.head_backward(P, hc, dpc, dpr, need_dpooled=True)
+        dF2 = dense.roi_crop_resize_bwd(F.shape, rois, 14, dpooled)
+        g_head.update(dense.base_backward(P, caches, dF2))
+        if detail is not None:
+            detail.update(F=F, R=R, sel=sel, g_head=g_head, dF_head=dF2, dpooled=dpooled)
+        self.opt_head.apply(P, g_head)
+        return [l_cls, l_regr, lc, lr_, dense.categorical_accuracy(Y1[:, sel].astype(np.float32), pc)]
+
+
 def _acc(total, g):
     if total is None:
         return {n: {k: v.astype(np.float64).copy() for k, v in d.items()} for n, d in g.items()}

@@ -265,3 +265,27 @@ def test_rpn_and_head_backward_vs_torch_autograd(params64):
     for n in names:
         for k in ("kernel", "bias"):
             assert np.allclose(grads[n][k], T[n][k].grad.numpy(), rtol=1e-6, atol=1e-9), (n, k)
+
+
+def test_base_backward_stages_3_4_vs_torch_autograd():
+    """cont_train.py trainability: gradients of every stage-3/4 conv given dL/dF, against torch autograd (float64)."""
+    P = dense.init_params(seed=3, dtype=np.float64)
+    names = dense.s34_trainable()
+    assert len(names) == 4 * 3 + 1 + 6 * 3 + 1 and all(n.startswith(("res3", "res4")) for n in names)
+    T = {n: {k: _t(v).clone().requires_grad_(n in names) for k, v in d.items()} for n, d in P.items()}
+    rs = np.random.RandomState(11)
+    x = rs.uniform(-120, 130, (1, 70, 90, 3))
+    F, caches = dense.base_forward(P, x, want_cache=True)
+    dF = rs.standard_normal(F.shape)
+    grads = dense.base_backward(P, caches, dF)
+    assert sorted(grads) == sorted(names)
+    y = _t_cbr(P, T, TF.pad(_t(x).permute(0, 3, 1, 2), (3, 3, 3, 3)), "conv1", "bn_conv1", stride=2)
+    y = TF.max_pool2d(y, 3, 2)
+    for st, blocks, _, stride in dense.RES_STAGES:
+        for bl in blocks:
+            y = _t_block(P, T, y, st, bl, stride, bl == "a")
+    (y.permute(0, 2, 3, 1) * _t(dF)).sum().backward()
+    for n in names:
+        for k in ("kernel", "bias"):
+            ref = T[n][k].grad.numpy()
+            assert np.allclose(grads[n][k], ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max())), (n, k)
