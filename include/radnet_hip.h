@@ -228,6 +228,12 @@ int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha);
 /* out[i] = a[i]*b[i] + c[i]: refreshes the folded epilogue shift (BN scale * conv bias + BN shift,
  * FixedBatchNormalization.py:59-85) of the trainable head convs after an optimizer step. */
 int radnet_affine_vec(radnet_ctx* ctx, float* out, const float* a, const float* b, const float* c, int64_t n);
+/* Input gradient of a stride-s 1x1 convolution (resnet50.py:100,111: the first 1x1 and the shortcut of every
+ * conv_block).  The GEMM runs on the compact grid -- radnet_conv_dgrad with a descriptor whose input geometry is
+ * the OUTPUT grid (h = oh, w = ow, stride 1) -- and this pass places its rows at (oh*s, ow*s) of the full
+ * [nb][h][w][c] gradient, zeros elsewhere, then applies the producer's ReLU mask (mask > 0) if given. */
+int radnet_scatter_strided(radnet_ctx* ctx, const float* src, int32_t nb, int32_t oh, int32_t ow, int32_t c, int32_t stride,
+                           int32_t h, int32_t w, const float* mask, float* dst);
 /* g[i] = act[i] > 0 ? g[i] : 0 -- ReLU backward where it cannot ride a GEMM epilogue (VGG16 head, vgg16.py:98-101) */
 int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
 

@@ -597,6 +597,43 @@ __global__ void __launch_bounds__(256) relu_mask_kernel(float* __restrict__ g, c
 }
 }  // namespace
 
+namespace {
+// dst pixel (ih, iw) of the full grid takes the compact source pixel (ih/s, iw/s) when both coordinates are multiples
+// of s (and inside the compact grid), zero otherwise; then the optional ReLU mask of the producer.
+__global__ void __launch_bounds__(256) scatter_strided_kernel(const float4* __restrict__ src, int nb, int oh, int ow, int c4, int s, int h, int w,
+                                                              const float4* __restrict__ mask, float4* __restrict__ dst) {
+  const long long total = (long long)nb * h * w * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    long long p = i / c4;
+    const int iw = (int)(p % w);
+    p /= w;
+    const int ih = (int)(p % h);
+    const int img = (int)(p / h);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int qh = ih / s, qw = iw / s;
+    if (qh * s == ih && qw * s == iw && qh < oh && qw < ow) v = src[(((long long)img * oh + qh) * ow + qw) * c4 + cc];
+    if (mask != nullptr) {
+      const float4 m = mask[i];
+      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    dst[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int radnet_scatter_strided(radnet_ctx* ctx, const float* src, int32_t nb, int32_t oh, int32_t ow, int32_t c, int32_t stride,
+                                      int32_t h, int32_t w, const float* mask, float* dst) {
+  if (!ctx || !src || !dst) return RADNET_ERR_ARG;
+  if (c % 4 || stride < 1 || (oh - 1) * stride >= h || (ow - 1) * stride >= w)
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "scatter_strided: c=%d stride=%d grid %dx%d into %dx%d", c, stride, oh, ow, h, w);
+  const long long total = (long long)nb * h * w * (c / 4);
+  hipLaunchKernelGGL(scatter_strided_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ctx->stream, (const float4*)src, nb, oh, ow, c / 4,
+                     stride, h, w, (const float4*)mask, (float4*)dst);
+  RADNET_CHECK_LAUNCH(ctx, "scatter_strided");
+  return RADNET_OK;
+}
+
 extern "C" int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n) {
   if (!ctx || !g || !act) return RADNET_ERR_ARG;
   long long b = (n + 255) / 256;

@@ -427,6 +427,18 @@ class FasterRCNNEngine:
             elif kind == "colsum":
                 g, m, n, ld, gs, out, acc = p
                 rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, acc)
+            elif kind == "scatter":        # strided 1x1 dgrad: compact rows -> full grid (+ producer's ReLU mask)
+                src, nb, oh, ow, c, st, hh, ww, mask, dst = p
+                rc = lib.radnet_scatter_strided(h, src, nb, oh, ow, c, st, hh, ww, mask, dst)
+            elif kind == "fill0":
+                ptr, nbytes = p
+                rc = lib.radnet_fill_zero(h, ptr, nbytes)
+            elif kind == "relu_mask":
+                g, act, n = p
+                rc = lib.radnet_relu_mask(h, g, act, n)
+            elif kind == "roi_bwd":
+                dy, hh, ww, c, rois, r, ps, dF = p
+                rc = lib.radnet_roi_resize_bwd(h, dy, hh, ww, c, rois, r, ps, dF)
             else:
                 raise L.RadnetError("unknown op " + kind)
             if rc != 0:
@@ -619,6 +631,7 @@ class FasterRCNNEngine:
                     d.ld_dx_mask = ld_dx
                 return d
 
+            B["g_out"], B["g_a"], B["g_b"] = g_out, g_a, g_b      # gradients w.r.t. this block's output / 2a / 2b outputs
             dC = bdesc(B["dc"], cc, g_out, f3, g_b, f2, None, B["b"])
             bwd += [("wgrad", dC), ("colsum", [g_out.data_ptr(), M, f3, f3, cc.scale.data_ptr(), cc.dbias.data_ptr(), 1]), ("dgrad", dC)]
             dB = bdesc(B["db"], cb, g_b, f2, g_a, f1, None, B["a"])

@@ -93,6 +93,7 @@ def load_library():
         "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32]),
         "radnet_affine_vec": (C.c_int, [vp, vp, vp, vp, vp, i64]),
         "radnet_relu_mask": (C.c_int, [vp, vp, vp, i64]),
+        "radnet_scatter_strided": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
         "radnet_proposals_ws_bytes": (u64, [i64]),
         "radnet_rpn_to_roi": (C.c_int, [vp, vp, i32, i32, i32, i32, C.POINTER(f64), f64, i32, f64, i32, vp, vp, vp, vp]),
         "radnet_nms": (C.c_int, [vp, vp, vp, i32, f64, i32, vp, vp, vp]),
