@@ -26,6 +26,7 @@ import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 ALGO_GFLOP_PER_IMAGE = 226.4       # minimal train step, base frozen (train.py semantics)
+ALGO_GFLOP_CONT = 537.0            # cont_train.py variant (stages 3-4 trainable in both models)
 
 
 def make_batch(rank, per_gpu, H, W):
@@ -74,6 +75,9 @@ def main():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--trainable", choices=("train", "cont"), default="train",
+                    help="train: train.py trainability, whole base frozen (the BASELINE metric); cont: cont_train.py, stages 3-4 "
+                         "unfrozen in both models (secondary measurement, single GPU)")
     ap.add_argument("--tune-cache", default=None,
                     help="file with measured GEMM launch choices: loaded when present (no trial launches), written after warm-up otherwise")
     args = ap.parse_args()
@@ -99,9 +103,33 @@ def main():
     from radnet_hip.trainer import TrainStep
 
     C = Config()
-    eng = FasterRCNNEngine(C, device_index=local_rank)
-    eng.set_weights(synth.synthetic_weights(seed=3))
-    ts = TrainStep(eng, world_size=world)
+    cont = args.trainable == "cont"
+    if cont:
+        if world != 1:
+            raise SystemExit("bench.py --trainable cont is single-GPU")
+        from radnet_hip.engine_cont import ContEngine
+        from radnet_hip.trainer_cont import ContTrainStep
+        eng = ContEngine(C, device_index=local_rank)
+        eng.set_weights(synth.synthetic_weights(seed=3))
+        _ts = ContTrainStep(eng)
+
+        class _Adapter:              # same calling convention as TrainStep for the loops below
+            skipped_head_steps = property(lambda self: _ts.skipped_head_steps)
+
+            def step(self, batch, next_batch=None):
+                return _ts.step(batch)
+
+            def flush(self):
+                pass
+
+            def losses(self):
+                return _ts.losses()
+
+        ts = _Adapter()
+    else:
+        eng = FasterRCNNEngine(C, device_index=local_rank)
+        eng.set_weights(synth.synthetic_weights(seed=3))
+        ts = TrainStep(eng, world_size=world)
     have_cache = args.tune_cache is not None and os.path.exists(args.tune_cache)
     if have_cache:
         eng.load_tuning(args.tune_cache)
@@ -168,10 +196,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full train step (RPN + RoiPoolingConv + classifier head + losses + 2x Adam), ResNet50, %dx%d, "
-                                   "batch=%d per GPU, base frozen (train.py)" % (args.width, args.height, args.per_gpu_batch),
+                                   "batch=%d per GPU, %s" % (args.width, args.height, args.per_gpu_batch,
+                                                              "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
                        "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
-                       "parallelism": "dp%d" % world, "algorithmic_gflop_per_image": ALGO_GFLOP_PER_IMAGE,
-                       "step_tflops_algorithmic": value / world * ALGO_GFLOP_PER_IMAGE / 1e3},
+                       "parallelism": "dp%d" % world, "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
+                       "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},
             "losses": losses,
         }
         if roof is not None:
