@@ -6,20 +6,23 @@ Differences from trainer.TrainStep (train.py mode, whole base frozen):
   * the classifier loss also drives stages 3-4 (through res5a, the RoI crop-resize and the feature map), Adam #2 applies
     to the head and, with its OWN moments, to the same stage-3/4 weights (cont_train.py:169-185).
 Mini-batch semantics as TrainStep: every image is an independent reference iteration on the same weights, each optimizer
-applies once with the mean gradient.  Single process (the data-parallel exchange would add the stage-3/4 arena to both
-all-reduces, SURVEY.md 8e: 52.2 MB and 93.3 MB).
+applies once with the mean gradient over all images of all ranks.  Data parallel: the stage-3/4 gradient arena joins both
+exchanges (19.0 + 33.2 MB before Adam #1, 60.1 + 33.2 MB before Adam #2), synchronously -- the base moves
+with both optimizers, so neither update can be deferred across the next step's base forward as in train.py mode.
 """
 import numpy as np
 import torch
 
 from . import engine as E
-from .trainer import new_img_size
+from .trainer import allreduce_grad_arena, new_img_size
 
 
 class ContTrainStep:
 
-    def __init__(self, eng):
+    def __init__(self, eng, dist_group=None, world_size=1):
         self.eng = eng
+        self.world = world_size
+        self.group = dist_group
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None
@@ -40,6 +43,7 @@ class ContTrainStep:
         eng = self.eng
         C = eng.C
         nloc = len(batch)
+        ntot = nloc * self.world
         tp, plans, rps = [], [], []
         for i, s in enumerate(batch):
             H, W = s["img"].shape[:2]
@@ -57,8 +61,10 @@ class ContTrainStep:
             eng.set_accumulate(plans[i]["bwd34"], i > 0, prezeroed=True)
             eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[i])      # ends with rpn_conv1's dgrad into plan['dF']
             eng.s34_backward(plans[i])
-        eng.adam(eng.rpn_arena, grad_scale=1.0 / nloc)
-        eng.adam_s34(0, grad_scale=1.0 / nloc)
+        allreduce_grad_arena(eng.rpn_arena.g, self.world, self.group)
+        allreduce_grad_arena(eng.s34_arena.g, self.world, self.group)
+        eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
+        eng.adam_s34(0, grad_scale=1.0 / ntot)
         # ---- classifier model on the moved base
         n_head = 0
         for i, bp in enumerate(plans):
@@ -86,10 +92,12 @@ class ContTrainStep:
             eng.head_backward(hp, accumulate=True, loss_out=self._det_l[n_head])   # ... -> RoI crop-resize -> plan['dF']
             eng.s34_backward(bp)
             n_head += 1
-        if n_head > 0:
-            eng.adam(eng.head_arena, grad_scale=1.0 / nloc)
+        if n_head > 0 or self.world > 1:          # a rank whose images all skipped still joins the exchange (zeros)
+            allreduce_grad_arena(eng.head_arena.g, self.world, self.group)
+            allreduce_grad_arena(eng.s34_arena.g, self.world, self.group)
+            eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
             eng.refresh_head_shift()
-            eng.adam_s34(1, grad_scale=1.0 / nloc)
+            eng.adam_s34(1, grad_scale=1.0 / ntot)
         self.last = (nloc, n_head)
         return self
 

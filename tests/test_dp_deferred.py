@@ -157,3 +157,73 @@ def test_deferred_head_update_order_and_value(defer):
             # immediate: before step k even starts
             assert (i_upd > i_rpn) == defer
         assert any(e[0] == "refresh" for e in log)
+
+
+class FakeContEngine(FakeEngine):
+    """What trainer_cont.ContTrainStep touches beyond FakeEngine: the shared stage-3/4 arena and its two optimizers."""
+
+    def __init__(self, rank):
+        super().__init__(rank)
+        self.s34_arena = _Arena(8)
+
+    def stem_forward(self, bp):
+        self.log.append(("stem_fwd", self.k))
+
+    def s34_forward(self, bp):
+        self.log.append(("s34_fwd", self.k, float(self.s34_arena.p[0])))
+
+    def upload_image(self, img, slot=0):
+        return dict(fh=2, fw=2, F=None, slot=slot, bwd34=[])
+
+    def s34_backward(self, bp):
+        self.s34_arena.g += float(10 * (self.rank + 1))
+
+    def adam_s34(self, which, grad_scale=1.0):
+        self.log.append(("adam_s34_%d" % which, self.k, float(self.s34_arena.g[0]) * grad_scale))
+        self.s34_arena.p -= grad_scale * self.s34_arena.g
+        self.s34_arena.g.zero_()
+
+    def roi_targets(self, R, Rn, gt, width, height, rw, rh):
+        return self.roi_targets_finish(self.roi_targets_launch(R, Rn, gt, width, height, rw, rh))
+
+
+def _cont_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "rock-art-radnet_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from radnet_hip.trainer_cont import ContTrainStep
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    np.random.seed(64 + rank)
+    eng = FakeContEngine(rank)
+    ts = ContTrainStep(eng, world_size=world)
+    batch = [dict(img=np.zeros((4, 4, 3), np.uint8), bboxes=[dict({"class": "fg"}, x1=0, x2=2, y1=0, y2=2)], width=8, height=8)]
+    for _ in range(2):
+        ts.step(batch)
+    out[rank] = (eng.log, eng.s34_arena.p.numpy().copy(), eng.head_arena.p.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_cont_mode_exchanges_the_shared_arena_before_both_optimizers():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cont_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (log0, s0, h0), (log1, s1, h1) = out[0], out[1]
+    assert np.array_equal(s0, s1) and np.array_equal(h0, h1)
+    # per step and per optimizer the shared arena receives (10 + 20) summed over ranks, scaled by 1/2: 15; two optimizers, two steps
+    assert np.allclose(s0, -4 * 15.0)
+    for log in (log0, log1):
+        upd = [e for e in log if e[0].startswith("adam_s34")]
+        assert [e[0] for e in upd] == ["adam_s34_0", "adam_s34_1"] * 2 and all(abs(e[2] - 15.0) < 1e-12 for e in upd)
+        # stages 3-4 run twice per step: before the RPN phase and again after Adam #1 moved them
+        fwd = [e for e in log if e[0] == "s34_fwd"]
+        assert np.allclose([e[2] for e in fwd], [0.0, -15.0, -30.0, -45.0])
+        assert sum(1 for e in log if e[0] == "stem_fwd") == 2
