@@ -144,6 +144,12 @@ def main():
     for _ in range(args.warmup):
         ts.step(batch, next_batch=batch)
     barrier()
+    # Everything long-lived exists now (plans, descriptors, graphs): collect once and move it to the permanent generation,
+    # so CPython's full collection -- measured at 41 ms here, i.e. twelve steps' worth of GPU idle -- does not fire at a
+    # random step of the run (tools/variance_probe.py).
+    import gc
+    gc.collect()
+    gc.freeze()
     if args.tune_cache is not None and not have_cache and rank == 0:
         eng.save_tuning(args.tune_cache)
     skipped0 = ts.skipped_head_steps

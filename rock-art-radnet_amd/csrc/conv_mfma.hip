@@ -1084,7 +1084,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int chunks[] = {1, 2, 3, 4, 5, 6, 8, 12};                 // K slices per tile
-    float best = 1e30f;
+    std::vector<std::pair<float, TileChoice>> seen;
     for (int c = 0; c < 4; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
       const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
@@ -1098,10 +1098,23 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
             int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
             if (rc == RADNET_ERR_UNSUPPORTED) continue;
             if (rc != RADNET_OK) return rc;
-            if (ms < best) { best = ms; tc = t; }
+            seen.push_back({ms, t});
           }
         }
       }
+    }
+    // The 3-launch screening above is noisy (neighbouring candidates differ by a few per cent, a shared host by more):
+    // the finalists are measured again, longer and twice, and the smaller figure of each decides.  Without this, two
+    // processes tuned different tables and the same commit benched 3.4 or 3.7 ms per step.
+    std::sort(seen.begin(), seen.end(), [](const std::pair<float, TileChoice>& a, const std::pair<float, TileChoice>& b) { return a.first < b.first; });
+    float best = 1e30f;
+    for (size_t i = 0; i < seen.size() && i < 4; ++i) {
+      float m1 = 0.f, m2 = 0.f;
+      int rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].second); }, 12, &m1);
+      if (rc == RADNET_OK) rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].second); }, 12, &m2);
+      if (rc != RADNET_OK) return rc;
+      const float ms = std::min(m1, m2);
+      if (ms < best) { best = ms; tc = seen[i].second; }
     }
     ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best, tc.waves};
     if (getenv("RADNET_TUNE_LOG"))
@@ -1211,7 +1224,8 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   } else if (it != ctx->tuned.end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
   } else if (ctx->autotune && d->dw_accumulate != 1) {
-    float best = 1e30f;
+    struct WCand { float ms; int bmk, bn, s; };
+    std::vector<WCand> seen;
     for (int cb = 128; cb >= 64; cb -= 64) {
       if (d->c % cb) continue;
       for (int cn = 128; cn >= 64; cn -= 64) {
@@ -1221,9 +1235,19 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
           float ms = 0.f;
           int rc = radnet_time_launches(ctx, [&]() { return launch(cb, cn, s); }, 3, &ms);
           if (rc != RADNET_OK) return rc;
-          if (ms < best) { best = ms; bmk = cb; bn = cn; splits = s; }
+          seen.push_back(WCand{ms, cb, cn, s});
         }
       }
+    }
+    std::sort(seen.begin(), seen.end(), [](const WCand& a, const WCand& b) { return a.ms < b.ms; });
+    float best = 1e30f;
+    for (size_t i = 0; i < seen.size() && i < 4; ++i) {        // finalists again, longer and twice (see run_igemm)
+      float m1 = 0.f, m2 = 0.f;
+      int rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].bmk, seen[i].bn, seen[i].s); }, 12, &m1);
+      if (rc == RADNET_OK) rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].bmk, seen[i].bn, seen[i].s); }, 12, &m2);
+      if (rc != RADNET_OK) return rc;
+      const float ms = std::min(m1, m2);
+      if (ms < best) { best = ms; bmk = seen[i].bmk; bn = seen[i].bn; splits = seen[i].s; }
     }
     ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best, 4};
     if (getenv("RADNET_TUNE_LOG"))
