@@ -1083,13 +1083,13 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     tc = TileChoice{it->second.a, it->second.b, it->second.splits, it->second.waves == 8 ? 8 : 4};
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    const int chunks[] = {1, 2, 3, 4, 5, 6, 8, 12};                 // K slices per tile
+    const int chunks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};      // K slices per tile
     std::vector<std::pair<float, TileChoice>> seen;
     for (int c = 0; c < 4; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
       const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
       for (int s : chunks) {
-        if (s > 1 && (ctx->ws == nullptr || nk / s < 4)) continue;              // slices shorter than 4 k-tiles
+        if (s > 1 && (ctx->ws == nullptr || nk / s < 2)) continue;               // slices shorter than 2 k-tiles
         for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
           if (sign < 0 && tiles * s < 16) continue;
           for (int waves = 4; waves <= 8; waves += 4) {                         // 8 = K tile halved between two wave grids
@@ -1108,7 +1108,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     // processes tuned different tables and the same commit benched 3.4 or 3.7 ms per step.
     std::sort(seen.begin(), seen.end(), [](const std::pair<float, TileChoice>& a, const std::pair<float, TileChoice>& b) { return a.first < b.first; });
     float best = 1e30f;
-    for (size_t i = 0; i < seen.size() && i < 4; ++i) {
+    for (size_t i = 0; i < seen.size() && i < 6; ++i) {
       float m1 = 0.f, m2 = 0.f;
       int rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].second); }, 12, &m1);
       if (rc == RADNET_OK) rc = radnet_time_launches(ctx, [&]() { return launch(seen[i].second); }, 12, &m2);
