@@ -4,23 +4,28 @@
 // of the reference graph (base_models/resnet50.py:41-147,183-186; rpn.py:41-64;
 // FixedBatchNormalization.py:59-85) and for the TF autodiff gradients of those layers.
 //
-// Design (MI355X-first, see DESIGN.md):
-//   * NHWC activations, weights [K=(kh,kw,c)][N]: the im2col matrix is never materialised; each
-//     workgroup gathers its A tile (BM output pixels x 32 k) straight from the activation tensor with
-//     16-byte loads (4 consecutive channels), zero-filling padding / out-of-range rows.
-//   * 256 threads = 4 wavefronts in a 2x2 arrangement; each wave owns a (BM/2)x(BN/2) block of the
-//     output as 32x32 MFMA tiles kept in accumulator registers for the whole K loop.
-//   * LDS holds both operands reduction-major ([k][m] and [k][n]) so that every MFMA operand
-//     fetch is one conflict-free ds_read_b32 per lane (lanes 0-31 = 32 consecutive rows/cols of
-//     k, lanes 32-63 = k+1).  The A tile is transposed on its way into LDS with a row pitch of
-//     BM+1 words (bank-conflict free for the 4x8 lane pattern of the store, see store_trans).
-//   * global loads of tile t+1 are issued before the MFMA loop of tile t and written to the other
-//     LDS buffer afterwards: one barrier per 32-deep K step.
-//   * epilogue fused: frozen-BN scale/shift (+bias), residual add, ReLU / sigmoid; for dgrad the
-//     residual-path gradient add and the producer's ReLU mask.
-//   * fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak), 16x less than bf16, so LDS and
-//     L2 bandwidth are far from limiting; what matters is filling 256 CUs at batch 1 -- hence the
-//     tile-shape selection and split-K in the launchers below.
+// Design (MI355X-first, see DESIGN.md 4):
+//   * NHWC activations, weights [K=(kh,kw,c)][N]: the im2col matrix is never materialised; each workgroup gathers
+//     its A tile (BM output pixels x 32 k) straight from the activation tensor with 16-byte buffer loads (4
+//     consecutive channels); padding taps, ragged rows / columns and tiles past the end are an out-of-range offset
+//     that the hardware answers with zeros -- no branch anywhere in the K loop.
+//   * 4 wavefronts in a 2x2 arrangement (optionally 8: two grids halving every K tile); each wave owns a
+//     (BM/2)x(BN/2) block of the output as 32x32 MFMA tiles in accumulator registers for the whole K loop.
+//   * LDS double buffer.  The gathered operand (A; both operands in dgrad) is ROW-major [row][36]: written with one
+//     ds_write_b128 per 4-k chunk, read 4 k at a time with ds_read_b128 -- the k order inside a tile is free as long
+//     as both operands agree (mfma_tile_rows).  Forward weights stay k-major [k][BN+4] (conflict-free ds_read_b32).
+//     wgrad keeps both operands reduction-major (mfma_tile).
+//   * two register stages of global loads (tile t+2 in flight while t is multiplied); loads, address arithmetic and
+//     LDS stores are single operations dealt out BETWEEN the MFMA steps: a wave cannot overlap its own VALU / memory
+//     instructions with its own MFMAs (tools/mfma_loop_probe.hip), so what counts is the non-MFMA instruction count
+//     per tile and having other waves on the SIMD.
+//   * epilogue fused through buffer descriptors: frozen-BN scale/shift (+bias), residual add, ReLU / sigmoid; for
+//     dgrad the residual-path gradient add and the producer's ReLU mask.
+//   * split-K inside the launch: slices write sc1 (write-through) slabs, take a ticket from a per-tile arrival
+//     counter, the last arriver reduces in slice order and applies the epilogue.
+//   * fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak), 16x less than bf16, so LDS and L2 bandwidth are far
+//     from limiting; what matters is filling 256 CUs at batch 1 -- tile shape, K slices, workgroup order and waves per
+//     workgroup are measured per problem shape (run_igemm).
 #include "radnet_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -115,18 +120,6 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
 }
 
 __device__ __forceinline__ float f4_comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-
-// ---- operand staging -----------------------------------------------------------------------------
-// transposed store: thread holds 4 consecutive-k values of one row; LDS layout [k][pitch] with
-// pitch == 1 (mod 32).  For a 32-lane half, rows t/8 (4 values) x kc=t%8 (8 values) hit bank
-// (4*kc + j + row) % 32: 32 distinct banks -> conflict free.
-__device__ __forceinline__ void store_trans(float* s, int pitch, int row, int kc, float4 v) {
-  float* p = s + (kc * 4) * pitch + row;
-  p[0] = v.x;
-  p[pitch] = v.y;
-  p[2 * pitch] = v.z;
-  p[3 * pitch] = v.w;
-}
 
 // One 32-deep K tile: 16 MFMA steps of depth 2, operand fragments prefetched from LDS into a register ring (one
 // wave per SIMD has nobody else to hide the LDS latency behind).
