@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradnet_hip.so")
+LIB_PATH = os.environ.get("RADNET_HIP_LIBRARY", os.path.join(_HERE, "libradnet_hip.so"))    # override: A/B builds, diag twin
 HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "..", "include", "radnet_hip.h"))
 
 c_float_p = C.c_void_p      # device pointers travel as integers
