@@ -175,6 +175,7 @@ def main():
     if args.roofline_steps > 0:
         eng.ctx.timing(True)
         eng.ctx.timing_reset()
+        eng.wino_timing[:] = [0.0, 0.0, 0]
         for _ in range(args.roofline_steps):
             ts.step(batch)
         torch.cuda.synchronize()
@@ -187,9 +188,16 @@ def main():
                          "tflops": fl / max(ms, 1e-9) / 1e9}
             tot_ms += ms; tot_fl += fl; tot_n += n
         eng.ctx.timing(False)
+        # 3x3 layers run as Winograd F(2x2,3x3) (input transform + 16 batched GEMMs on the same kernel + output transform):
+        # timed per LAYER, credited the layer's algorithmic 2*M*N*9C flops, not the 2.25x fewer it executes
+        wms, wfl, wn = eng.wino_timing
+        if wn:
+            per["conv3x3_winograd_layers"] = {"launches_per_step": wn / args.roofline_steps / args.per_gpu_batch, "avg_us": 1e3 * wms / wn,
+                                              "tflops": wfl / max(wms, 1e-9) / 1e9}
+            tot_ms += wms; tot_fl += wfl
         ach = tot_fl / max(tot_ms, 1e-9) / 1e9
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
                 "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,
                 "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}
     if dist is not None:

@@ -105,6 +105,17 @@ typedef struct radnet_conv_desc {
 } radnet_conv_desc;
 
 int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d);
+/* Strided-batched fp32 GEMM on the same matrix-core kernel: y[p][m][n] = a[p][m][k] * b[p][k][n], p < batch, all
+ * operands dense row-major and contiguous over p; k a multiple of 32, n of 4. */
+int radnet_gemm_batched(radnet_ctx* ctx, const float* a, const float* b, float* y, int32_t batch, int32_t m, int32_t n, int32_t k);
+/* Winograd F(2x2,3x3) form of a stride-1 'same' 3x3 convolution (same layers as radnet_conv_fwd; 2.25x fewer matrix-core
+ * flops): u = filter transform of w [3][3][c][ldw] -> [16][c][n] (once per weight update); v = input transform of
+ * x [nb][h][w][c] -> [16][tiles][c], tiles = nb*ceil(h/2)*ceil(w/2); radnet_gemm_batched(v, u, m, 16, tiles, n, c);
+ * output transform of m [16][tiles][n] with the conv epilogue: y = act(conv * scale + shift), act 0 none / 1 relu. */
+int radnet_winograd_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u);
+int radnet_winograd_input(radnet_ctx* ctx, const float* x, int32_t nb, int32_t h, int32_t w, int32_t c, float* v);
+int radnet_winograd_output(radnet_ctx* ctx, const float* m, int32_t nb, int32_t oh, int32_t ow, int32_t n, const float* scale,
+                           const float* shift, int32_t act, float* y, int32_t ldy);
 int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 

@@ -64,6 +64,8 @@ struct GemmArgs {
   int OHOW;
   unsigned x_bytes, w_bytes;   // extents for the buffer descriptors
   unsigned y_bytes, add_bytes, mask_bytes;
+  int batch;                   // > 1: blockIdx.z selects one of `batch` independent GEMMs (plain launches only)
+  long long x_bstride, w_bstride, y_bstride;   // floats between consecutive problems of a batch
   unsigned* counters;          // K-split launches: arrival counter per output tile (zero outside a launch)
   unsigned long long* stamps;  // diagnostic build only (RADNET_DIAG_STAMPS): 8 words per workgroup
 };
@@ -329,8 +331,10 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     kw_run = pos - kh_run * g.KW;
   }
 
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w, g.w_bytes);
+  // batched launch (radnet_gemm_batched): problem blockIdx.z of a strided batch, same geometry
+  const long long bz = g.batch > 1 ? (long long)blockIdx.z : 0;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x + bz * g.x_bstride, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w + bz * g.w_bstride, g.w_bytes);
   const bool has_in_scale = g.in_scale != nullptr;
   const __amdgpu_buffer_rsrc_t rscale = make_rsrc(g.in_scale, has_in_scale ? (unsigned)g.C * 4u : 0u);
   // Two register stages: the loads of tile t+2 are issued while tile t is being multiplied and tile t+1 waits in the
@@ -619,7 +623,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   // with 0 for loads and drops for stores.  All 16 residual (and mask) loads of a 32x32 tile are issued back to back
   // before the first store, so their latency is paid once per tile instead of once per register (a conditional
   // load -> store chain cannot be reordered by the compiler: y may alias the addend).
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(g.y, g.y_bytes);
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(g.y + bz * g.y_bstride, g.y_bytes);
   const __amdgpu_buffer_rsrc_t radd = make_rsrc(g.addend, g.addend ? g.add_bytes : 0u);     // null -> every load returns 0
   const __amdgpu_buffer_rsrc_t rmask = make_rsrc(g.mask, g.mask ? g.mask_bytes : 0u);
   const bool has_mask = g.mask != nullptr;
@@ -1003,7 +1007,7 @@ void launch_igemm_w(hipStream_t st, const GemmArgs& g, const TileChoice& tc, dim
 
 template <int BMODE, bool SMALLC>
 void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n_units) {
-  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), 1);
+  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), g.batch > 1 ? g.batch : 1);
   if (g.units != nullptr) grid = dim3(n_units, 1, 1);
   if (tc.waves == 8) launch_igemm_w<BMODE, SMALLC, 8>(st, g, tc, grid);
   else launch_igemm_w<BMODE, SMALLC, 4>(st, g, tc, grid);
@@ -1043,6 +1047,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.units = nullptr;
     g.partial = nullptr;
     g.counters = nullptr;
+    if (g.batch > 1 && t.splits != 1) return RADNET_ERR_UNSUPPORTED;      // a batch is its own source of workgroups
     if (t.splits > 1 || t.splits < 0) {
       tb = get_unit_table(ctx, g.M, g.N, g.K, t.bm, t.bn, t.splits);
       if (!tb) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv: cannot build the work-unit table");
@@ -1066,7 +1071,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     return RADNET_OK;
   };
   // tile / split-K choice: measured once per problem shape when autotuning is on, else the cost model
-  const radnet_shape_key key{cls == 1 ? 1 : 0, g.M, g.N, g.K, g.C, g.npos, g.stride};
+  const radnet_shape_key key{g.batch > 1 ? 8 : (cls == 1 ? 1 : 0), g.M, g.N, g.K, g.C, g.npos, g.batch > 1 ? g.batch : g.stride};
   TileChoice tc{64, 64, 1};
   auto it = ctx->tuned.find(key);
   if (ctx->force_a > 0) {                      // radnet_force_config: tests sweep every tile / slice / order variant
@@ -1114,12 +1119,12 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       fprintf(stderr, "[radnet tune] %s M=%d N=%d K=%d C=%d -> tile %dx%d chunks %d waves %d : %.1f us (%.1f TFLOP/s)\n", cls == 1 ? "dgrad" : "fwd",
               g.M, g.N, g.K, g.C, tc.bm, tc.bn, tc.splits, tc.waves, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
   } else {
-    tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr);
+    tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr && g.batch <= 1);
   }
   radnet_timing_begin(ctx);
   int rc = launch(tc);
   if (rc != RADNET_OK) return rc;
-  radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K);
+  radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K * (g.batch > 1 ? g.batch : 1));
   return RADNET_OK;
 }
 
@@ -1150,6 +1155,21 @@ extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   if ((d->oh - 1) * d->stride - d->pad_t >= d->h || (d->ow - 1) * d->stride - d->pad_l >= d->w_)
     RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_fwd: output %dx%d inconsistent with input %dx%d", d->oh, d->ow, d->h, d->w_);
   return run_igemm(ctx, g, 0, d->c == 4, 0);
+}
+
+extern "C" int radnet_gemm_batched(radnet_ctx* ctx, const float* a, const float* b, float* y, int32_t batch, int32_t m, int32_t n, int32_t k) {
+  if (!ctx || !a || !b || !y) return RADNET_ERR_ARG;
+  if (batch < 1 || batch > 65535) RADNET_FAIL(ctx, RADNET_ERR_ARG, "gemm_batched: batch %d", batch);
+  GemmArgs g{};
+  g.x = a; g.w = b; g.y = y;
+  g.H = 1; g.W = m; g.C = k; g.OH = 1; g.OW = m;           // a 1x1 convolution over m 'pixels' of k channels
+  g.KW = 1; g.npos = 1; g.stride = 1; g.pad_t = 0; g.pad_l = 0;
+  g.M = m; g.N = n; g.K = k;
+  g.ldw = n; g.ldy = n; g.ld_add = 0; g.ld_mask = 0;
+  g.OHOW = m;
+  g.batch = batch;
+  g.x_bstride = (long long)m * k; g.w_bstride = (long long)k * n; g.y_bstride = (long long)m * n;
+  return run_igemm(ctx, g, 0, false, 0);
 }
 
 extern "C" int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {

@@ -1,0 +1,175 @@
+// Winograd F(2x2, 3x3) transforms for the stride-1 'same' 3x3 convolutions (resnet50.py:53,104: conv_block /
+// identity_block 2b; rpn.py:41-48 rpn_conv1).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g, per (c, n)
+//
+// turns 36 multiplications per output tile and channel pair into 16: the 16 element-wise products, summed over the
+// input channels, are 16 independent GEMMs [tiles x C] x [C x N] on the fp32 matrix cores (radnet_gemm_batched), 2.25x
+// fewer MFMA flops than the direct implicit GEMM at the price of three HBM-bound passes (input transform 1 read + 4x
+// write, output transform 4x read + 1 write, filter transform once per weight update).  It pays where K = 9*C is large
+// against the activation size: rpn_conv1 (C = 1024) and the stage-5 3x3 convs (C = 512).
+// Arithmetic: the transforms are exact in the sense of using only additions and multiplications by 1/2 (B and A have
+// entries 0, +-1; G has 1/2); results differ from the direct sum by fp32 rounding (different association), well inside
+// the stated 1e-3 activation tolerance (tests compare against the oracle's direct convolution).
+#include "radnet_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4half(float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
+
+// U[p][c][n] = (G g G^T)[p], p = 4*xi + nu.  g: [3][3][C][ldw] (Keras HWIO flattened), one thread per (c, 4 n).
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ g, int C, int N, int ldw, float* __restrict__ U) {
+  const int n4 = N >> 2;
+  const long long total = (long long)C * n4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+    float4 w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) w[a][b] = *reinterpret_cast<const float4*>(g + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
+    // t = G w  (4x3), rows: w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2
+    float4 t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = w[0][b];
+      t[1][b] = f4half(f4add(f4add(w[0][b], w[1][b]), w[2][b]));
+      t[2][b] = f4half(f4add(f4sub(w[0][b], w[1][b]), w[2][b]));
+      t[3][b] = w[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 u0 = t[a][0], u1 = f4half(f4add(f4add(t[a][0], t[a][1]), t[a][2])), u2 = f4half(f4add(f4sub(t[a][0], t[a][1]), t[a][2])), u3 = t[a][2];
+      float4* dst = reinterpret_cast<float4*>(U + ((long long)(a * 4) * C + c) * N + nq * 4);
+      const long long ps = (long long)C * N / 4;      // float4 stride between consecutive p
+      dst[0] = u0; dst[ps] = u1; dst[2 * ps] = u2; dst[3 * ps] = u3;
+    }
+  }
+}
+
+// V[p][tile][c] = (B^T d B)[p]; tile = (img, ti, tj) covers outputs (2ti..2ti+1, 2tj..2tj+1), input patch rows
+// 2ti-1 .. 2ti+2 (pad 1).  One thread per (tile, 4 channels).
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, int nb, int H, int W, int C, int TH, int TW,
+                                                         float* __restrict__ V) {
+  const int c4 = C >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const long long tile = i / c4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    float4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int ih = 2 * ti - 1 + a;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int iw = 2 * tj - 1 + b;
+        d[a][b] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                      ? *reinterpret_cast<const float4*>(x + (((long long)img * H + ih) * W + iw) * C + cq * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // t = B^T d: rows d0-d2, d1+d2, d2-d1, d1-d3
+    float4 t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      t[0][b] = f4sub(d[0][b], d[2][b]);
+      t[1][b] = f4add(d[1][b], d[2][b]);
+      t[2][b] = f4sub(d[2][b], d[1][b]);
+      t[3][b] = f4sub(d[1][b], d[3][b]);
+    }
+    const long long ps = T * c4;                        // float4 stride between consecutive p
+    float4* dst = reinterpret_cast<float4*>(V) + tile * c4 + cq;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      dst[(4 * a + 0) * ps] = f4sub(t[a][0], t[a][2]);
+      dst[(4 * a + 1) * ps] = f4add(t[a][1], t[a][2]);
+      dst[(4 * a + 2) * ps] = f4sub(t[a][2], t[a][1]);
+      dst[(4 * a + 3) * ps] = f4sub(t[a][1], t[a][3]);
+    }
+  }
+}
+
+// y = act( (A^T m A) * scale + shift ) for the 2x2 outputs of each tile; Mm: [16][T][N].  One thread per (tile, 4 n).
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mm, int nb, int OH, int OW, int N, int TH, int TW,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                          float* __restrict__ y, int ldy) {
+  const int n4 = N >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * n4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int nq = (int)(i % n4);
+    const long long tile = i / n4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    const long long ps = T * n4;
+    const float4* src = reinterpret_cast<const float4*>(Mm) + tile * n4 + nq;
+    float4 m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) m[a][b] = src[(4 * a + b) * ps];
+    // t = A^T m: rows m0+m1+m2, m1-m2-m3
+    float4 t[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      t[0][b] = f4add(f4add(m[0][b], m[1][b]), m[2][b]);
+      t[1][b] = f4sub(f4sub(m[1][b], m[2][b]), m[3][b]);
+    }
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + nq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oh = 2 * ti + a;
+      if (oh >= OH) continue;
+      const float4 o[2] = {f4add(f4add(t[a][0], t[a][1]), t[a][2]), f4sub(f4sub(t[a][1], t[a][2]), t[a][3])};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ow = 2 * tj + b;
+        if (ow >= OW) continue;
+        float4 v = make_float4(o[b].x * sc.x + sh.x, o[b].y * sc.y + sh.y, o[b].z * sc.z + sh.z, o[b].w * sc.w + sh.w);
+        if (act == 1) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *reinterpret_cast<float4*>(y + (((long long)img * OH + oh) * OW + ow) * ldy + nq * 4) = v;
+      }
+    }
+  }
+}
+
+inline int grid_of(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int radnet_winograd_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u) {
+  if (!ctx || !w || !u) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_filter: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, w, c, n, ldw, u);
+  RADNET_CHECK_LAUNCH(ctx, "winograd_filter");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd_input(radnet_ctx* ctx, const float* x, int32_t nb, int32_t h, int32_t w, int32_t c, float* v) {
+  if (!ctx || !x || !v) return RADNET_ERR_ARG;
+  if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_input: c=%d must be a multiple of 4", c);
+  const int th = (h + 1) / 2, tw = (w + 1) / 2;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_of((long long)nb * th * tw * (c / 4))), dim3(256), 0, ctx->stream, x, nb, h, w, c, th, tw, v);
+  RADNET_CHECK_LAUNCH(ctx, "winograd_input");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd_output(radnet_ctx* ctx, const float* m, int32_t nb, int32_t oh, int32_t ow, int32_t n, const float* scale,
+                                      const float* shift, int32_t act, float* y, int32_t ldy) {
+  if (!ctx || !m || !y) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_output: n=%d, ldy=%d", n, ldy);
+  const int th = (oh + 1) / 2, tw = (ow + 1) / 2;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, m, nb, oh, ow, n, th, tw, scale,
+                     shift, act, y, ldy);
+  RADNET_CHECK_LAUNCH(ctx, "winograd_output");
+  return RADNET_OK;
+}

@@ -87,6 +87,7 @@ class ConvLayer:
         self.t0 = None          # BN shift without the conv bias (trainable convs refresh shift = scale*bias + t0)
         self.dweight = None
         self.dbias = None
+        self.wino_u = None      # Winograd-transformed filter [16][cin][cout] when the layer runs as F(2x2,3x3)
 
 
 class FasterRCNNEngine:
@@ -118,6 +119,8 @@ class FasterRCNNEngine:
         self._plans = {}
         self._graphs = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
+        self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
+        self.wino_timing = [0.0, 0.0, 0]        # ms, algorithmic flops, layers -- filled while ctx.timing is on (bench roofline leg)
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
         self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
@@ -273,6 +276,7 @@ class FasterRCNNEngine:
         b[:self.nc] = dc["bias"]; b[self.nc:self.nc + self.nreg] = dr["bias"]
         self.dense_w.copy_(t(k)); self.dense_b.copy_(t(b))
         self.refresh_head_shift()
+        self._refresh_winograd()
         torch.cuda.synchronize(self.dev)
 
     def get_weights(self, names=None):
@@ -308,6 +312,40 @@ class FasterRCNNEngine:
         d.act_cols = act_cols
         return d, oh, ow
 
+    # Winograd F(2x2,3x3) for the 3x3 layers where it measured faster than the direct implicit GEMM at 1000x600
+    # (tools/winograd_timing.py: rpn_conv1 201 -> 119 us, res4x_2b 39 -> 34, res3x_2b 40 -> 37; stage 2 loses, the
+    # trainable stage-5 convs would pay a filter transform per step).  Trainable layers re-transform after Adam.
+    WINOGRAD_LAYERS = ("rpn_conv1",) + tuple("res%d%s_branch2b" % (st, bl) for st, bls in ((3, "abcd"), (4, "abcdef")) for bl in bls)
+
+    def _uses_winograd(self, c):
+        return self.use_winograd and c.name in self.WINOGRAD_LAYERS and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
+
+    def _refresh_winograd(self, names=None):
+        """Filter transform U = G g G^T of the Winograd layers (all of them, or the named ones after a weight update)."""
+        for name in (names if names is not None else self.WINOGRAD_LAYERS):
+            c = self.convs.get(name)
+            if c is None or not self._uses_winograd(c):
+                continue
+            if c.wino_u is None:
+                c.wino_u = torch.empty(16, c.cin, c.cout, dtype=torch.float32, device=self.dev)
+            self.ctx.call("radnet_winograd_filter", c.weight, c.cin, c.cout, c.ldw, c.wino_u)
+
+    def _fwd_op(self, c, x, nb, h, w, y, keep, relu=True):
+        """Forward op of conv `c` on x -> y: the direct implicit GEMM, or the Winograd form for the layers listed above."""
+        d, oh, ow = self._desc(c, x, nb, h, w, y, relu=relu)
+        if not self._uses_winograd(c):
+            return ("conv", d), d
+        if c.wino_u is None:
+            self._refresh_winograd([c.name])
+        T = nb * ((h + 1) // 2) * ((w + 1) // 2)
+        V = torch.empty(16, T, c.cin, dtype=torch.float32, device=self.dev)
+        M = torch.empty(16, T, c.cout, dtype=torch.float32, device=self.dev)
+        keep += [V, M]
+        op = ("wino", (x.data_ptr(), nb, h, w, c.cin, c.cout, V.data_ptr(), c.wino_u.data_ptr(), M.data_ptr(), T,
+                       c.scale.data_ptr() if c.scale is not None else None, c.shift.data_ptr() if c.shift is not None else None,
+                       1 if relu else 0, y.data_ptr(), c.cout))
+        return op, d
+
     def _plan_base(self, nb, H, W, slot=0):
         """Static launch list of nn_base for (nb,H,W) input: [(kind, payload)], output tensor F.
         `slot` selects an independent buffer set (one per image of a per-GPU mini-batch)."""
@@ -341,7 +379,7 @@ class FasterRCNNEngine:
                 a = buf(nb, oh, ow, f1)
                 d, _, _ = self._desc(ca, cur, nb, h, w, a); ops.append(("conv", d))
                 bb = buf(nb, oh, ow, f2)
-                d, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", d))
+                op, _ = self._fwd_op(cb, a, nb, oh, ow, bb, keep); ops.append(op)
                 if first:
                     sc = buf(nb, oh, ow, f3)
                     d, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False); ops.append(("conv", d))
@@ -429,6 +467,25 @@ class FasterRCNNEngine:
             elif kind == "colsum":
                 g, m, n, ld, gs, out, acc = p
                 rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, acc)
+            elif kind == "wino":           # stride-1 'same' 3x3 conv as Winograd F(2x2,3x3): transform, 16 GEMMs, transform
+                x, nb, hh, ww, c, n, V, U, M, T, scale, shift, act, y, ldy = p
+                timed = self.ctx.timing_on
+                if timed:                  # roofline leg: the LAYER is timed (three kernels) and credited its algorithmic flops
+                    self.ctx.timing(False)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = lib.radnet_winograd_input(h, x, nb, hh, ww, c, V)
+                if rc == 0:
+                    rc = lib.radnet_gemm_batched(h, V, U, M, 16, T, n, c)
+                if rc == 0:
+                    rc = lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
+                if timed:
+                    e1.record()
+                    e1.synchronize()
+                    self.wino_timing[0] += e0.elapsed_time(e1)
+                    self.wino_timing[1] += 2.0 * nb * hh * ww * n * 9 * c
+                    self.wino_timing[2] += 1
+                    self.ctx.timing(True)
             elif kind == "scatter":        # strided 1x1 dgrad: compact rows -> full grid (+ producer's ReLU mask)
                 src, nb, oh, ow, c, st, hh, ww, mask, dst = p
                 rc = lib.radnet_scatter_strided(h, src, nb, oh, ow, c, st, hh, ww, mask, dst)
@@ -532,7 +589,8 @@ class FasterRCNNEngine:
         hbuf = torch.empty(1, fh, fw, 512, dtype=torch.float32, device=dev)
         pred = torch.empty(M, RPN_LD, dtype=torch.float32, device=dev)
         c1, ch = self.convs["rpn_conv1"], self.convs["rpn_heads"]
-        d1, _, _ = self._desc(c1, F, 1, fh, fw, hbuf, relu=True)
+        wino_keep = []
+        op1, d1 = self._fwd_op(c1, F, 1, fh, fw, hbuf, wino_keep, relu=True)
         d2, _, _ = self._desc(ch, hbuf, 1, fh, fw, pred, act=2, act_cols=self.A)
         # backward
         dz = torch.zeros(M, RPN_LD, dtype=torch.float32, device=dev)
@@ -549,7 +607,7 @@ class FasterRCNNEngine:
                ("dgrad", b2), ("wgrad", b1), ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
         bwd = self._fuse_bias_grads(bwd)
         ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
-        plan = dict(fwd=[("conv", d1), ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw,
+        plan = dict(fwd=[op1, ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
                     R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
                     Rn=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -573,6 +631,8 @@ class FasterRCNNEngine:
         arena.t += 1
         self.ctx.call("radnet_adam_step", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
                       C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0)
+        if arena is self.rpn_arena:
+            self._refresh_winograd(["rpn_conv1"])          # its forward runs on the transformed filter
 
     def zero_grads(self, arena):
         self.ctx.call("radnet_fill_zero", arena.g, C.c_uint64(arena.n * 4))

@@ -79,6 +79,10 @@ def load_library():
         "radnet_timing_reset": (C.c_int, [vp]),
         "radnet_conv_fwd": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_conv_dgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
+        "radnet_gemm_batched": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),
+        "radnet_winograd_filter": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "radnet_winograd_input": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+        "radnet_winograd_output": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
         "radnet_conv_wgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_colsum": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i32]),
         "radnet_maxpool_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),

@@ -455,3 +455,32 @@ def test_roi_targets_golden(ctx):
         got, ref = y2.cpu().numpy(), Y2[0].astype(np.float32)
         assert np.array_equal(got[:, :24], ref[:, :24])
         assert np.allclose(got[:, 24:], ref[:, 24:], rtol=2e-7, atol=0)      # log: device vs NumPy, 1 ulp of fp64 -> <= 1 ulp fp32
+
+
+@pytest.mark.parametrize("case", [(1, 38, 63, 1024, 512), (20, 7, 7, 512, 512), (2, 9, 12, 64, 128)])
+def test_winograd_conv3x3_vs_oracle(ctx, case):
+    """Winograd F(2x2,3x3) path (filter / input transform, 16 batched GEMMs, output transform with the BN-ReLU epilogue)
+    against the oracle's direct 3x3 'same' convolution; odd sizes exercise the partial border tiles."""
+    from oracle import dense
+    nb, h, w, cin, cout = case
+    rs = np.random.RandomState(sum(case))
+    x = np.maximum(rs.standard_normal((nb, h, w, cin)), 0).astype(np.float32)
+    wt = (rs.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    sc = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rs.standard_normal(cout).astype(np.float32)
+    ref = np.maximum(dense.conv2d(x.astype(np.float64), wt.astype(np.float64), None, 1, (1, 1, 1, 1)) * sc + sh, 0)
+    T = nb * ((h + 1) // 2) * ((w + 1) // 2)
+    U = torch.empty(16, cin, cout, device="cuda")
+    V = torch.empty(16, T, cin, device="cuda")
+    M = torch.empty(16, T, cout, device="cuda")
+    y = torch.full((nb, h, w, cout), float("nan"), device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.radnet_set_workspace(ctx.h, ws.data_ptr(), ws.numel()), "ws")
+    ctx.call("radnet_winograd_filter", dev(wt.reshape(-1, cout)), cin, cout, cout, U)
+    ctx.call("radnet_winograd_input", dev(x), nb, h, w, cin, V)
+    ctx.call("radnet_gemm_batched", V, U, M, 16, T, cout, cin)
+    ctx.call("radnet_winograd_output", M, nb, h, w, cout, dev(sc), dev(sh), 1, y, cout)
+    close(y.cpu().numpy(), ref)
+    # the batched GEMM on its own
+    mref = np.einsum("ptc,pcn->ptn", V.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
+    close(M.cpu().numpy(), mref)
