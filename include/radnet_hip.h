@@ -116,6 +116,15 @@ int radnet_winograd_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n
 int radnet_winograd_input(radnet_ctx* ctx, const float* x, int32_t nb, int32_t h, int32_t w, int32_t c, float* v);
 int radnet_winograd_output(radnet_ctx* ctx, const float* m, int32_t nb, int32_t oh, int32_t ow, int32_t n, const float* scale,
                            const float* shift, int32_t act, float* y, int32_t ldy);
+/* Weight gradient of the same layers in the Winograd domain: dz = A dY A^T per tile of the (gscale-scaled) output gradient
+ * [nb][oh][ow][ld_dy] -> [16][tiles][n]; radnet_wgrad_batched(v, dz, du, 16, tiles, c, n, 0): du[p][c][n] = sum over tiles of
+ * v[p][tile][c] * dz[p][tile][n] with the v of the forward pass; dw [3][3][c][ldw] (+)= G^T du G.  The bias gradient is the
+ * plain column sum of dy (radnet_colsum). */
+int radnet_winograd_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh, int32_t ow, int32_t n, int32_t ld_dy,
+                       const float* gscale, float* dz);
+int radnet_wgrad_batched(radnet_ctx* ctx, const float* a, const float* dy, float* dw, int32_t batch, int32_t m, int32_t k, int32_t n,
+                         int32_t accumulate);
+int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate);
 int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 

@@ -681,6 +681,8 @@ struct WgradArgs {
   int atomic;
   const int2* rowtab;    // [M] {byte offset of the row's window origin, ih0 | iw0 << 16}, see get_row_table
   unsigned x_bytes, dy_bytes;
+  int batch, splits;     // batch > 1: blockIdx.z = problem * splits + split (radnet_wgrad_batched)
+  long long x_bstride, dy_bstride, dw_bstride;   // floats between consecutive problems
 };
 
 template <int BMK, int BN>
@@ -712,12 +714,14 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   if (g.gscale != nullptr && b_nv) gs = *reinterpret_cast<const float4*>(g.gscale + n0 + b_n4 * 4);
 
   const int nmt = (g.M + BK - 1) / BK;
-  const int mt_begin = blockIdx.z * g.mt_per_split;
+  const int zsplit = g.batch > 1 ? (int)(blockIdx.z % (unsigned)g.splits) : (int)blockIdx.z;
+  const long long bp = g.batch > 1 ? (long long)(blockIdx.z / (unsigned)g.splits) : 0;
+  const int mt_begin = zsplit * g.mt_per_split;
   int mt_end = mt_begin + g.mt_per_split;
   if (mt_end > nmt) mt_end = nmt;
 
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, g.x_bytes);
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(g.dy, g.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x + bp * g.x_bstride, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(g.dy + bp * g.dy_bstride, g.dy_bytes);
   float4 ra[A_ITERS], rb[B_ITERS];
   // bias gradient: the workgroups of the first k tile see every (dy * gscale) row of their m range exactly once on
   // its way into LDS; they keep a running column sum and add it to db at the end (keras Conv2D bias / the beta-free
@@ -865,7 +869,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int k = k0 + wm * (BMK / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (n < g.N && k < g.K) {
-          float* p = g.dw + (size_t)k * g.ldw + n;
+          float* p = g.dw + bp * g.dw_bstride + (size_t)k * g.ldw + n;
           if (g.atomic) atomicAdd(p, acc[i][j][r]);
           else *p = acc[i][j][r];
         }
@@ -1191,10 +1195,11 @@ extern "C" int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   return run_igemm(ctx, g, 1, false, 1);
 }
 
-extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
+static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long long x_bs, long long dy_bs, long long dw_bs) {
   if (!ctx || !d) return RADNET_ERR_ARG;
   if (!d->x || !d->dy || !d->dw) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: null tensor");
   WgradArgs g{};
+  g.batch = batch; g.x_bstride = x_bs; g.dy_bstride = dy_bs; g.dw_bstride = dw_bs;
   g.x = d->x; g.dy = d->dy; g.gscale = d->gscale; g.dw = d->dw; g.db = nullptr;
   g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow; g.KW = d->kw;
   g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
@@ -1215,12 +1220,13 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
   const int nmt = radnet_cdiv(g.M, BK);
   auto launch = [&](int bmk, int bn, int splits) -> int {
     g.mt_per_split = radnet_cdiv(nmt, splits);
+    g.splits = splits;
     // dw_accumulate: 0 = overwrite, 1 = add to existing contents, 2 = destination is pre-zeroed by the caller
     // (plain stores when un-split, atomics without the memset when split)
     g.atomic = (splits > 1 || d->dw_accumulate == 1) ? 1 : 0;
     if (splits > 1 && d->dw_accumulate == 0)  // atomics need a zeroed destination
-      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (size_t)g.K * g.ldw * sizeof(float), ctx->stream));
-    dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits), block(NTHREADS);
+      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (batch > 1 ? (size_t)batch * dw_bs : (size_t)g.K * g.ldw) * sizeof(float), ctx->stream));
+    dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits * (batch > 1 ? batch : 1)), block(NTHREADS);
     if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
     else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
     else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
@@ -1229,7 +1235,7 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
     return RADNET_OK;
   };
   int bmk = (d->c % 128 == 0) ? 128 : 64, bn = g.N > 64 ? 128 : 64, splits = 1;
-  const radnet_shape_key key{2 + (d->dw_accumulate == 1 ? 1 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
+  const radnet_shape_key key{2 + (d->dw_accumulate == 1 ? 1 : 0) + (batch > 1 ? 16 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, batch > 1 ? batch : g.stride};
   auto it = ctx->tuned.find(key);
   if (ctx->force_a > 0) {
     bmk = ctx->force_a; bn = ctx->force_b; splits = ctx->force_splits < 1 ? 1 : ctx->force_splits;
@@ -1292,6 +1298,22 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) {
     if (rc != RADNET_OK) return rc;
   }
   RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
-  radnet_timing_end(ctx, 2, 2.0 * g.M * g.N * g.K);
+  radnet_timing_end(ctx, 2, 2.0 * g.M * g.N * g.K * (batch > 1 ? batch : 1));
   return RADNET_OK;
 }
+
+extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) { return run_wgrad(ctx, d, 1, 0, 0, 0); }
+
+extern "C" int radnet_wgrad_batched(radnet_ctx* ctx, const float* a, const float* dy, float* dw, int32_t batch, int32_t m, int32_t k, int32_t n,
+                                    int32_t accumulate) {
+  if (!ctx || !a || !dy || !dw) return RADNET_ERR_ARG;
+  if (batch < 1 || batch > 4096) RADNET_FAIL(ctx, RADNET_ERR_ARG, "wgrad_batched: batch %d", batch);
+  radnet_conv_desc d{};
+  d.x = a; d.dy = dy; d.dw = dw;
+  d.nb = 1; d.h = 1; d.w_ = m; d.c = k; d.oh = 1; d.ow = m;      // a 1x1 convolution over m 'pixels' of k channels
+  d.kh = 1; d.kw = 1; d.stride = 1; d.pad_t = 0; d.pad_l = 0; d.n = n;
+  d.ldw = n; d.ld_dy = n;
+  d.dw_accumulate = accumulate;
+  return run_wgrad(ctx, &d, batch, (long long)m * k, (long long)m * n, (long long)k * n);
+}
+

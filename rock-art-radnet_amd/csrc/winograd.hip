@@ -139,6 +139,88 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
   }
 }
 
+// ---- weight gradient in the Winograd domain -------------------------------------------------------------------------
+// Y = A^T Z A, Z[p] = sum_c U[p] V[p]  =>  dU[p][c][n] = sum_tiles V[p][tile][c] * dZ[p][tile][n] with dZ = A dY A^T (16
+// reduction-over-tiles GEMMs, radnet_wgrad_batched, on the V the forward pass already produced), then dg = G^T dU G.
+// dZ[p][tile][n] for the 2x2 output-gradient block of each tile (outputs past the edge contribute 0), dy scaled by the
+// per-channel factor gscale (frozen-BN scale) when given.
+__global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, int nb, int OH, int OW, int N, int ld_dy, int TH, int TW,
+                                                      const float* __restrict__ gscale, float* __restrict__ dZ) {
+  const int n4 = N >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * n4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int nq = (int)(i % n4);
+    const long long tile = i / n4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    const float4 gs = gscale ? *reinterpret_cast<const float4*>(gscale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oh = 2 * ti + a, ow = 2 * tj + b;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oh < OH && ow < OW) v = *reinterpret_cast<const float4*>(dy + (((long long)img * OH + oh) * OW + ow) * ld_dy + nq * 4);
+        d[a][b] = make_float4(v.x * gs.x, v.y * gs.y, v.z * gs.z, v.w * gs.w);
+      }
+    // r = A d (4x2): d0, d0+d1, d0-d1, -d1
+    float4 r[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      r[0][b] = d[0][b];
+      r[1][b] = f4add(d[0][b], d[1][b]);
+      r[2][b] = f4sub(d[0][b], d[1][b]);
+      r[3][b] = f4sub(make_float4(0.f, 0.f, 0.f, 0.f), d[1][b]);
+    }
+    const long long ps = T * n4;
+    float4* dst = reinterpret_cast<float4*>(dZ) + tile * n4 + nq;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      dst[(4 * a + 0) * ps] = r[a][0];
+      dst[(4 * a + 1) * ps] = f4add(r[a][0], r[a][1]);
+      dst[(4 * a + 2) * ps] = f4sub(r[a][0], r[a][1]);
+      dst[(4 * a + 3) * ps] = f4sub(make_float4(0.f, 0.f, 0.f, 0.f), r[a][1]);
+    }
+  }
+}
+
+// dw[3][3][C][ldw] (+)= G^T dU G, dU: [16][C][N]
+__global__ void __launch_bounds__(256) wino_filter_grad_kernel(const float* __restrict__ dU, int C, int N, int ldw, float* __restrict__ dw, int accumulate) {
+  const int n4 = N >> 2;
+  const long long total = (long long)C * n4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+    const long long ps = (long long)C * n4;
+    const float4* src = reinterpret_cast<const float4*>(dU) + (long long)c * n4 + nq;
+    float4 u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) u[a][b] = src[(4 * a + b) * ps];
+    // t = G^T u (3x4): u0 + (u1+u2)/2, (u1-u2)/2, (u1+u2)/2 + u3
+    float4 t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 hs = f4half(f4add(u[1][b], u[2][b])), hd = f4half(f4sub(u[1][b], u[2][b]));
+      t[0][b] = f4add(u[0][b], hs);
+      t[1][b] = hd;
+      t[2][b] = f4add(hs, u[3][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float4 hs = f4half(f4add(t[a][1], t[a][2])), hd = f4half(f4sub(t[a][1], t[a][2]));
+      const float4 g3[3] = {f4add(t[a][0], hs), hd, f4add(hs, t[a][3])};
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float4* p = reinterpret_cast<float4*>(dw + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
+        *p = accumulate ? f4add(*p, g3[b]) : g3[b];
+      }
+    }
+  }
+}
+
 inline int grid_of(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -173,3 +255,23 @@ extern "C" int radnet_winograd_output(radnet_ctx* ctx, const float* m, int32_t n
   RADNET_CHECK_LAUNCH(ctx, "winograd_output");
   return RADNET_OK;
 }
+
+extern "C" int radnet_winograd_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh, int32_t ow, int32_t n, int32_t ld_dy,
+                                  const float* gscale, float* dz) {
+  if (!ctx || !dy || !dz) return RADNET_ERR_ARG;
+  if ((n & 3) || (ld_dy & 3) || ld_dy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_dy: n=%d, ld_dy=%d", n, ld_dy);
+  const int th = (oh + 1) / 2, tw = (ow + 1) / 2;
+  hipLaunchKernelGGL(wino_dy_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, dy, nb, oh, ow, n, ld_dy, th, tw,
+                     gscale, dz);
+  RADNET_CHECK_LAUNCH(ctx, "winograd_dy");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate) {
+  if (!ctx || !du || !dw) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_filter_grad: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  hipLaunchKernelGGL(wino_filter_grad_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, du, c, n, ldw, dw, accumulate ? 1 : 0);
+  RADNET_CHECK_LAUNCH(ctx, "winograd_filter_grad");
+  return RADNET_OK;
+}
+

@@ -120,6 +120,7 @@ class FasterRCNNEngine:
         self._graphs = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
+        self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.wino_timing = [0.0, 0.0, 0]        # ms, algorithmic flops, layers -- filled while ctx.timing is on (bench roofline leg)
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
@@ -408,7 +409,7 @@ class FasterRCNNEngine:
         the host thread stays ahead of the GPU (tools/host_timeline.py).  Keyed by the program and the gradient
         write modes of its wgrad descriptors (set_accumulate edits them in place)."""
         overlap = overlap and self.overlap_wgrad and not self.ctx.timing_on      # timed launches run one at a time
-        key = (id(ops), overlap, tuple(p.dw_accumulate for kind, p in ops if kind == "wgrad"))
+        key = (id(ops), overlap, tuple(p.dw_accumulate if kind == "wgrad" else p[-1] for kind, p in ops if kind in ("wgrad", "wino_wgrad")))
         ent = self._graphs.get(key)
         if ent is None:
             # first run of this program: every new GEMM shape is measured here, so launches run one at a time
@@ -486,6 +487,25 @@ class FasterRCNNEngine:
                     self.wino_timing[1] += 2.0 * nb * hh * ww * n * 9 * c
                     self.wino_timing[2] += 1
                     self.ctx.timing(True)
+            elif kind == "wino_wgrad":     # weight gradient of a Winograd layer in the transformed domain, on the forward's V
+                dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, mode = p
+                timed = self.ctx.timing_on
+                if timed:
+                    self.ctx.timing(False)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = lib.radnet_winograd_dy(h, dy, nb, hh, ww, n, ld_dy, None, dZ)
+                if rc == 0:
+                    rc = lib.radnet_wgrad_batched(h, V, dZ, dU, 16, T, c, n, 0)
+                if rc == 0:
+                    rc = lib.radnet_winograd_filter_grad(h, dU, c, n, ldw, dw, 1 if mode == 1 else 0)
+                if timed:
+                    e1.record()
+                    e1.synchronize()
+                    self.wino_timing[0] += e0.elapsed_time(e1)
+                    self.wino_timing[1] += 2.0 * nb * hh * ww * n * 9 * c
+                    self.wino_timing[2] += 1
+                    self.ctx.timing(True)
             elif kind == "scatter":        # strided 1x1 dgrad: compact rows -> full grid (+ producer's ReLU mask)
                 src, nb, oh, ow, c, st, hh, ww, mask, dst = p
                 rc = lib.radnet_scatter_strided(h, src, nb, oh, ow, c, st, hh, ww, mask, dst)
@@ -529,6 +549,8 @@ class FasterRCNNEngine:
         for kind, p in ops:
             if kind == "wgrad":
                 p.dw_accumulate = v
+            elif kind == "wino_wgrad":
+                p[-1] = v
             elif kind == "colsum":
                 p[6] = 1 if (flag or prezeroed) else 0
 
@@ -603,11 +625,21 @@ class FasterRCNNEngine:
         b1 = L.ConvDesc.from_buffer_copy(d1)
         b1.dy, b1.ld_dy, b1.gscale = dh.data_ptr(), 512, None
         b1.dw, b1.dw_accumulate = c1.dweight.data_ptr(), 1
+        if op1[0] == "wino" and self.wino_wgrad:
+            # dW in the Winograd domain on the V of the forward pass (F does not change between forward and backward)
+            V, T = wino_keep[0], wino_keep[0].shape[1]
+            dZ = torch.empty(16, T, c1.cout, dtype=torch.float32, device=dev)
+            dU = torch.empty(16, c1.cin, c1.cout, dtype=torch.float32, device=dev)
+            wino_keep += [dZ, dU]
+            wg1 = ("wino_wgrad", [dh.data_ptr(), 1, fh, fw, c1.cin, c1.cout, 512, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T,
+                                  c1.dweight.data_ptr(), c1.ldw, 1])
+        else:
+            wg1 = ("wgrad", b1)
         bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),
-               ("dgrad", b2), ("wgrad", b1), ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
+               ("dgrad", b2), wg1, ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
         bwd = self._fuse_bias_grads(bwd)
         ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
-        plan = dict(fwd=[op1, ("conv", d2)], bwd=bwd, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
+        plan = dict(fwd=[op1, ("conv", d2)], bwd=bwd, b1=b1, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
                     R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
                     Rn=torch.zeros(1, dtype=torch.int32, device=dev))

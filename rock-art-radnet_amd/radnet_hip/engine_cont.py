@@ -212,7 +212,7 @@ class ContEngine(FasterRCNNEngine):
         rp = super()._plan_rpn(fh, fw, F)
         if "cont" not in rp:
             base = self._base_of_F[F.data_ptr()]
-            b1 = [p for kind, p in rp["bwd"] if kind == "wgrad"][-1]        # rpn_conv1's backward descriptor
+            b1 = rp["b1"]                                                   # rpn_conv1's backward descriptor
             b1.dx, b1.ld_dx, b1.dx_add, b1.dx_mask, b1.ld_dx_mask = base["dF"].data_ptr(), 1024, None, F.data_ptr(), 1024
             rp["bwd"].append(("dgrad", b1))
             rp["cont"] = True

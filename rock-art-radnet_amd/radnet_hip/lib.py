@@ -83,6 +83,9 @@ def load_library():
         "radnet_winograd_filter": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_winograd_input": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "radnet_winograd_output": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
+        "radnet_winograd_dy": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+        "radnet_wgrad_batched": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+        "radnet_winograd_filter_grad": (C.c_int, [vp, vp, i32, i32, i32, vp, i32]),
         "radnet_conv_wgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_colsum": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i32]),
         "radnet_maxpool_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),

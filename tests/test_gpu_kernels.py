@@ -484,3 +484,29 @@ def test_winograd_conv3x3_vs_oracle(ctx, case):
     # the batched GEMM on its own
     mref = np.einsum("ptc,pcn->ptn", V.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
     close(M.cpu().numpy(), mref)
+
+
+@pytest.mark.parametrize("case", [(1, 38, 63, 1024, 512), (2, 9, 11, 64, 128)])
+def test_winograd_wgrad_vs_oracle(ctx, case):
+    """Weight gradient of a 3x3 'same' conv in the Winograd domain (dy transform, 16 reduction-over-tiles GEMMs on the
+    forward pass's transformed input, inverse filter transform) against the oracle's direct gradient."""
+    from oracle import dense
+    nb, h, w, cin, cout = case
+    rs = np.random.RandomState(sum(case) + 5)
+    x = np.maximum(rs.standard_normal((nb, h, w, cin)), 0).astype(np.float32)
+    dy = rs.standard_normal((nb, h, w, cout)).astype(np.float32)
+    gs = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    wt = np.zeros((3, 3, cin, cout), np.float32)
+    _, dw_ref, _ = dense.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), (dy * gs).astype(np.float64), 1, (1, 1, 1, 1), need_dx=False)
+    T = nb * ((h + 1) // 2) * ((w + 1) // 2)
+    V = torch.empty(16, T, cin, device="cuda")
+    dZ = torch.empty(16, T, cout, device="cuda")
+    dU = torch.full((16, cin, cout), float("nan"), device="cuda")
+    dw = torch.full((9 * cin, cout), float("nan"), device="cuda")
+    ctx.call("radnet_winograd_input", dev(x), nb, h, w, cin, V)
+    ctx.call("radnet_winograd_dy", dev(dy), nb, h, w, cout, cout, dev(gs), dZ)
+    ctx.call("radnet_wgrad_batched", V, dZ, dU, 16, T, cin, cout, 0)
+    ctx.call("radnet_winograd_filter_grad", dU, cin, cout, cout, dw, 0)
+    close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
+    ctx.call("radnet_winograd_filter_grad", dU, cin, cout, cout, dw, 1)          # accumulate: doubles
+    close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
