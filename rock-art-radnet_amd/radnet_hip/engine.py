@@ -12,6 +12,7 @@ Graph restated from the reference (never imported):
   step   train.py:288-402                              RPN train -> re-predict -> propose/label/sample -> head train
 """
 import ctypes as C
+import contextlib
 import os
 import math
 
@@ -134,7 +135,11 @@ class FasterRCNNEngine:
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self.ctx2 = L.Context(device_index, stream_handle=self.side_stream.cuda_stream)
         self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
+        if os.environ.get("RADNET_SIDE_NO_WS", "0") != "1":
+            self.ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
+            self.ctx2.check(self.lib.radnet_set_workspace(self.ctx2.h, self.ws2.data_ptr(), self.ws2.numel()), "set_workspace")
         self.overlap_wgrad = os.environ.get("RADNET_OVERLAP_WGRAD", "0") == "1"
+        self._side_done = None
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
         self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)
@@ -402,6 +407,28 @@ class FasterRCNNEngine:
         for c in (self.ctx, self.ctx2):
             c.check(self.lib.radnet_tune_load(c.h, path.encode()), "radnet_tune_load")
 
+    @contextlib.contextmanager
+    def on_side_stream(self):
+        """Everything enqueued inside runs on the side stream (own context: own split-K slabs, counters and tuning
+        tables), after what the main stream holds now; join_side() makes the main stream wait for it."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side_stream.wait_event(ev)
+        self.ctx, self.ctx2 = self.ctx2, self.ctx
+        try:
+            with torch.cuda.stream(self.side_stream):
+                yield
+                done = torch.cuda.Event()
+                done.record()
+        finally:
+            self.ctx, self.ctx2 = self.ctx2, self.ctx
+        self._side_done = done
+
+    def join_side(self):
+        if self._side_done is not None:
+            torch.cuda.current_stream().wait_event(self._side_done)
+            self._side_done = None
+
     def _run(self, ops, overlap=False):
         """Run a layer program (overlap: its wgrad launches go to the side stream, see __init__).  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
         autotunes every new GEMM shape and builds its work-unit tables -- the launch sequence is recorded into a
@@ -409,7 +436,7 @@ class FasterRCNNEngine:
         the host thread stays ahead of the GPU (tools/host_timeline.py).  Keyed by the program and the gradient
         write modes of its wgrad descriptors (set_accumulate edits them in place)."""
         overlap = overlap and self.overlap_wgrad and not self.ctx.timing_on      # timed launches run one at a time
-        key = (id(ops), overlap, tuple(p.dw_accumulate if kind == "wgrad" else p[-1] for kind, p in ops if kind in ("wgrad", "wino_wgrad")))
+        key = (id(ops), id(self.ctx), overlap, tuple(p.dw_accumulate if kind == "wgrad" else p[-1] for kind, p in ops if kind in ("wgrad", "wino_wgrad")))
         ent = self._graphs.get(key)
         if ent is None:
             # first run of this program: every new GEMM shape is measured here, so launches run one at a time

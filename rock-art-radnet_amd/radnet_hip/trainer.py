@@ -13,6 +13,8 @@ Batch semantics (the reference is batch-1 only): every image is an independent r
 gradient is the mean over all images of all ranks (SURVEY.md 8d cfg 4).  The order of draws from NumPy's
 global RNG is the reference's: subsampling of image 0..B-1, then sample selection of image 0..B-1.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -63,6 +65,8 @@ class TrainStep:
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self._pre = None                 # phases A/B of the next batch, enqueued ahead (step(next_batch=...))
         self._parity = 0                 # buffer set the next _launch_ab uses
+        # the prefetched phases A/B run on the engine's side stream, concurrently with this step's head phase
+        self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "on_side_stream")
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
@@ -142,6 +146,8 @@ class TrainStep:
         else:
             st = self._launch_ab(batch, self._parity)
         self._pre = None
+        if self.side_prefetch:
+            eng.join_side()
         self._parity = st["parity"] ^ 1
         tp, plans, rps = st["tp"], st["plans"], st["rps"]
         mark("B: upload + base + rpn forward enqueued")
@@ -165,7 +171,12 @@ class TrainStep:
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
             P = eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)
             if next_batch is not None and i == nloc - 1:
-                self._pre = self._launch_ab(next_batch, self._parity)      # keeps the GPU busy across the sync below
+                # keeps the GPU busy across the sync below -- and, on the side stream, next to the head phase
+                if self.side_prefetch and not eng.ctx.timing_on:
+                    with eng.on_side_stream():
+                        self._pre = self._launch_ab(next_batch, self._parity)
+                else:
+                    self._pre = self._launch_ab(next_batch, self._parity)
             mark("D: rpn re-predict + proposals + roi targets enqueued")
             P, cls, n = eng.roi_targets_finish(P)                             # the step's one host sync in this phase
             mark("D: roi classes on host")
