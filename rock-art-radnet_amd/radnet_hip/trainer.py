@@ -102,13 +102,12 @@ class TrainStep:
             s["_gt_dev"] = self.eng.upload_gt(boxes, isbg, cls)
         return s["_gt_dev"]
 
-    def _launch_ab(self, batch, parity):
-        """Device half of phase A (anchor labelling + async copy of the label maps) and phase B (upload, base forward,
-        RPN forward) of every image of `batch`, into the buffer set `parity`.  Touches frozen base weights and RPN
-        weights only."""
+    def _launch_a(self, batch, parity):
+        """Device half of phase A (anchor labelling + async copy of the label maps) and the weight-independent part of
+        phase B (upload, frozen base forward) of every image of `batch`, into the buffer set `parity`."""
         eng = self.eng
         nloc = len(batch)
-        tp, plans, rps = [], [], []
+        tp, plans = [], []
         for i, s in enumerate(batch):
             H, W = s["img"].shape[:2]
             tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=parity * nloc + i))
@@ -116,8 +115,15 @@ class TrainStep:
             bp = eng.upload_image(s["img"], slot=parity * nloc + i)
             eng.base_forward(bp)
             plans.append(bp)
-            rps.append(eng.rpn_forward(bp))
-        return dict(batch=batch, tp=tp, plans=plans, rps=rps, parity=parity)
+        return dict(batch=batch, tp=tp, plans=plans, rps=None, parity=parity)
+
+    def _launch_b(self, st):
+        """RPN forward of every image of a batch whose base forward is enqueued: reads the RPN weights."""
+        st["rps"] = [self.eng.rpn_forward(bp) for bp in st["plans"]]
+        return st
+
+    def _launch_ab(self, batch, parity):
+        return self._launch_b(self._launch_a(batch, parity))
 
     def step(self, batch, next_batch=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
@@ -150,6 +156,12 @@ class TrainStep:
             eng.join_side()
         self._parity = st["parity"] ^ 1
         tp, plans, rps = st["tp"], st["plans"], st["rps"]
+        # side-stream prefetch: the next batch's labelling kernels and frozen base forward need nothing from this step,
+        # so they start now, beside this step's RPN backward / proposal / head phases; its RPN forward follows Adam #1
+        early = self.side_prefetch and next_batch is not None and not eng.ctx.timing_on
+        if early:
+            with eng.on_side_stream():
+                self._pre = self._launch_a(next_batch, self._parity)
         mark("B: upload + base + rpn forward enqueued")
         # ---- phase A (host half, overlapped with B) + phase C
         # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
@@ -160,6 +172,9 @@ class TrainStep:
             eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[i])
         self._allreduce(eng.rpn_arena)
         eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
+        if early:
+            with eng.on_side_stream():
+                self._launch_b(self._pre)
         mark("C: rpn backward + adam enqueued")
         # ---- phase D: re-predict with updated weights, propose, label, sample, head train
         n_head = 0
@@ -170,13 +185,8 @@ class TrainStep:
             R, Rn = eng.proposals(rp, overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
             P = eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)
-            if next_batch is not None and i == nloc - 1:
-                # keeps the GPU busy across the sync below -- and, on the side stream, next to the head phase
-                if self.side_prefetch and not eng.ctx.timing_on:
-                    with eng.on_side_stream():
-                        self._pre = self._launch_ab(next_batch, self._parity)
-                else:
-                    self._pre = self._launch_ab(next_batch, self._parity)
+            if next_batch is not None and i == nloc - 1 and not early:
+                self._pre = self._launch_ab(next_batch, self._parity)      # keeps the GPU busy across the sync below
             mark("D: rpn re-predict + proposals + roi targets enqueued")
             P, cls, n = eng.roi_targets_finish(P)                             # the step's one host sync in this phase
             mark("D: roi classes on host")
