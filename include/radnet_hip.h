@@ -53,6 +53,9 @@ int radnet_tuned_shapes(radnet_ctx* ctx);
 /* Persist / restore the measured choices (text, one shape per line).  A context that loaded a table runs no trial
  * launches for the shapes in it: restarts skip the tuning step, and a profiler sees steady-state launches only. */
 int radnet_tune_save(radnet_ctx* ctx, const char* path);
+/* `ctx` uses (reads and extends) the table of `owner` from now on: the contexts an engine keeps for its concurrent lanes
+ * (one per HIP stream) measure every shape once.  All calls on contexts that share a table come from one host thread. */
+int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner);
 int radnet_tune_load(radnet_ctx* ctx, const char* path);
 /* Test hook: force every following conv GEMM launch to use output tile (tile_a x tile_b in {64,128}) and `slices` K
  * slices per tile (negative = same slices with the XCD-aware workgroup order); tile_a = 0 switches it off. */

@@ -57,14 +57,20 @@ extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
   return RADNET_OK;
 }
 
-extern "C" int radnet_tuned_shapes(radnet_ctx* ctx) { return ctx ? (int)ctx->tuned.size() : -1; }
+extern "C" int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner) {
+  if (!ctx || !owner) return RADNET_ERR_ARG;
+  ctx->tuned = owner->tuned;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_tuned_shapes(radnet_ctx* ctx) { return ctx ? (int)ctx->tuned->size() : -1; }
 
 extern "C" int radnet_tune_save(radnet_ctx* ctx, const char* path) {
   if (!ctx || !path) return RADNET_ERR_ARG;
   FILE* f = fopen(path, "w");
   if (!f) RADNET_FAIL(ctx, RADNET_ERR_ARG, "tune_save: cannot open %s", path);
   fprintf(f, "# radnet tuned GEMM launch shapes v2: kind m n k c npos stride | tile_a tile_b slices ms waves\n");
-  for (const auto& kv : ctx->tuned)
+  for (const auto& kv : *ctx->tuned)
     fprintf(f, "%d %d %d %d %d %d %d %d %d %d %.6f %d\n", kv.first.kind, kv.first.m, kv.first.n, kv.first.k, kv.first.c, kv.first.npos,
             kv.first.stride, kv.second.a, kv.second.b, kv.second.splits, (double)kv.second.ms, kv.second.waves);
   fclose(f);
@@ -88,7 +94,7 @@ extern "C" int radnet_tune_load(radnet_ctx* ctx, const char* path) {
     t.waves = waves == 8 ? 8 : 4;
     if ((t.a != 64 && t.a != 128) || (t.b != 64 && t.b != 128) || t.splits == 0 || t.splits > 64 || t.splits < -64) continue;
     t.ms = (float)ms;
-    ctx->tuned[k] = t;
+    (*ctx->tuned)[k] = t;
     ++n;
   }
   fclose(f);

@@ -1077,11 +1077,11 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   // tile / split-K choice: measured once per problem shape when autotuning is on, else the cost model
   const radnet_shape_key key{g.batch > 1 ? 8 : (cls == 1 ? 1 : 0), g.M, g.N, g.K, g.C, g.npos, g.batch > 1 ? g.batch : g.stride};
   TileChoice tc{64, 64, 1};
-  auto it = ctx->tuned.find(key);
+  auto it = ctx->tuned->find(key);
   if (ctx->force_a > 0) {                      // radnet_force_config: tests sweep every tile / slice / order variant
     tc = TileChoice{ctx->force_a, ctx->force_b, ctx->force_splits, ctx->force_waves == 8 ? 8 : 4};
     if (tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
-  } else if (it != ctx->tuned.end()) {
+  } else if (it != ctx->tuned->end()) {
     tc = TileChoice{it->second.a, it->second.b, it->second.splits, it->second.waves == 8 ? 8 : 4};
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
@@ -1118,7 +1118,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       const float ms = std::min(m1, m2);
       if (ms < best) { best = ms; tc = seen[i].second; }
     }
-    ctx->tuned[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best, tc.waves};
+    (*ctx->tuned)[key] = radnet_tuned{tc.bm, tc.bn, tc.splits, best, tc.waves};
     if (getenv("RADNET_TUNE_LOG"))
       fprintf(stderr, "[radnet tune] %s M=%d N=%d K=%d C=%d -> tile %dx%d chunks %d waves %d : %.1f us (%.1f TFLOP/s)\n", cls == 1 ? "dgrad" : "fwd",
               g.M, g.N, g.K, g.C, tc.bm, tc.bn, tc.splits, tc.waves, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
@@ -1127,6 +1127,10 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   }
   radnet_timing_begin(ctx);
   int rc = launch(tc);
+  if (rc == RADNET_ERR_UNSUPPORTED && ctx->force_a <= 0) {      // a shared / loaded choice whose slabs exceed THIS context's workspace
+    tc.splits = tc.splits < 0 ? -1 : 1;
+    rc = launch(tc);
+  }
   if (rc != RADNET_OK) return rc;
   radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K * (g.batch > 1 ? g.batch : 1));
   return RADNET_OK;
@@ -1236,11 +1240,11 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   };
   int bmk = (d->c % 128 == 0) ? 128 : 64, bn = g.N > 64 ? 128 : 64, splits = 1;
   const radnet_shape_key key{2 + (d->dw_accumulate == 1 ? 1 : 0) + (batch > 1 ? 16 : 0), g.M, g.N, g.K, g.C, d->kh * d->kw, batch > 1 ? batch : g.stride};
-  auto it = ctx->tuned.find(key);
+  auto it = ctx->tuned->find(key);
   if (ctx->force_a > 0) {
     bmk = ctx->force_a; bn = ctx->force_b; splits = ctx->force_splits < 1 ? 1 : ctx->force_splits;
     if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced k tile %d does not divide c=%d", bmk, d->c);
-  } else if (it != ctx->tuned.end()) {
+  } else if (it != ctx->tuned->end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
   } else if (ctx->autotune && d->dw_accumulate != 1) {
     struct WCand { float ms; int bmk, bn, s; };
@@ -1268,7 +1272,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
       const float ms = std::min(m1, m2);
       if (ms < best) { best = ms; bmk = seen[i].bmk; bn = seen[i].bn; splits = seen[i].s; }
     }
-    ctx->tuned[key] = radnet_tuned{bmk, bn, splits, best, 4};
+    (*ctx->tuned)[key] = radnet_tuned{bmk, bn, splits, best, 4};
     if (getenv("RADNET_TUNE_LOG"))
       fprintf(stderr, "radnet tune: wgrad M=%d N=%d K=%d C=%d -> tile %dx%d slices %d : %.1f us (%.1f TFLOP/s)\n", g.M, g.N, g.K, g.C,
               bmk, bn, splits, best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e9));
@@ -1277,8 +1281,8 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   } else {
     // accumulate mode reuses the overwrite-mode measurement when there is one
     const radnet_shape_key k0{2, g.M, g.N, g.K, g.C, d->kh * d->kw, g.stride};
-    auto it0 = ctx->tuned.find(k0);
-    if (it0 != ctx->tuned.end()) {
+    auto it0 = ctx->tuned->find(k0);
+    if (it0 != ctx->tuned->end()) {
       bmk = it0->second.a; bn = it0->second.b; splits = it0->second.splits;
     } else {
       long long tiles = (long long)radnet_cdiv(g.K, bmk) * radnet_cdiv(g.N, bn);

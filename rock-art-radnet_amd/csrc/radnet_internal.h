@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <memory>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -44,7 +45,8 @@ struct radnet_unit_table {
 struct radnet_ctx {
   int autotune = 0;
   int force_a = 0, force_b = 0, force_splits = 0, force_waves = 0;      // radnet_force_config (tests): overrides tuned / heuristic choices
-  std::map<radnet_shape_key, radnet_tuned> tuned;
+  // measured launch choices; contexts of one engine share ONE table (radnet_share_tuning), calls come from one host thread
+  std::shared_ptr<std::map<radnet_shape_key, radnet_tuned>> tuned = std::make_shared<std::map<radnet_shape_key, radnet_tuned>>();
   std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
   std::map<std::array<int, 9>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)
   hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;

@@ -135,11 +135,17 @@ class FasterRCNNEngine:
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self.ctx2 = L.Context(device_index, stream_handle=self.side_stream.cuda_stream)
         self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
-        if os.environ.get("RADNET_SIDE_NO_WS", "0") != "1":
-            self.ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
-            self.ctx2.check(self.lib.radnet_set_workspace(self.ctx2.h, self.ws2.data_ptr(), self.ws2.numel()), "set_workspace")
+        self.ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
+        self.ctx2.check(self.lib.radnet_set_workspace(self.ctx2.h, self.ws2.data_ptr(), self.ws2.numel()), "set_workspace")
         self.overlap_wgrad = os.environ.get("RADNET_OVERLAP_WGRAD", "0") == "1"
-        self._side_done = None
+        self.head_stream = torch.cuda.Stream(device=self.dev)
+        self.ctx3 = L.Context(device_index, stream_handle=self.head_stream.cuda_stream)
+        self.ctx3.check(self.lib.radnet_set_autotune(self.ctx3.h, 1 if autotune else 0), "set_autotune")
+        self.ws3 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
+        self.ctx3.check(self.lib.radnet_set_workspace(self.ctx3.h, self.ws3.data_ptr(), self.ws3.numel()), "set_workspace")
+        self._lanes = {"side": (self.ctx2, self.side_stream), "head": (self.ctx3, self.head_stream)}
+        for c in (self.ctx2, self.ctx3):           # one table of measured launch choices for all lanes
+            self.ctx.check(self.lib.radnet_share_tuning(c.h, self.ctx.h), "share_tuning")
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
         self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)
@@ -287,6 +293,7 @@ class FasterRCNNEngine:
 
     def get_weights(self, names=None):
         """Trainable weights back in Keras layout (host numpy)."""
+        torch.cuda.synchronize()                   # updates may be in flight on the head lane
         out = {}
         for name in ["rpn_conv1"] + self.head_conv_names:
             c = self.convs[name]
@@ -399,35 +406,39 @@ class FasterRCNNEngine:
         return plan
 
     def save_tuning(self, path):
-        """Write the measured GEMM launch choices of this engine (main context) to a text file."""
+        """Write the measured GEMM launch choices of this engine (one table for all lanes) to a text file."""
         self.ctx.check(self.lib.radnet_tune_save(self.ctx.h, path.encode()), "radnet_tune_save")
 
     def load_tuning(self, path):
         """Restore choices written by save_tuning: no trial launches for the shapes in the file."""
-        for c in (self.ctx, self.ctx2):
-            c.check(self.lib.radnet_tune_load(c.h, path.encode()), "radnet_tune_load")
+        self.ctx.check(self.lib.radnet_tune_load(self.ctx.h, path.encode()), "radnet_tune_load")
 
     @contextlib.contextmanager
-    def on_side_stream(self):
-        """Everything enqueued inside runs on the side stream (own context: own split-K slabs, counters and tuning
-        tables), after what the main stream holds now; join_side() makes the main stream wait for it."""
+    def lane(self, name):
+        """Everything enqueued inside goes to lane `name`: its own HIP stream and its own context (split-K slabs,
+        arrival counters, tuning tables -- two launches of one shape may be in flight at once).  'side' carries the next
+        batch's frozen base forward, 'head' the classifier phase; the caller orders lanes with mark() / after()."""
+        ctx, stream = self._lanes[name]
+        prev = self.ctx
+        self.ctx = ctx
+        try:
+            with torch.cuda.stream(stream):
+                yield
+        finally:
+            self.ctx = prev
+
+    @staticmethod
+    def mark():
+        """Event after everything enqueued so far on the current lane."""
         ev = torch.cuda.Event()
         ev.record()
-        self.side_stream.wait_event(ev)
-        self.ctx, self.ctx2 = self.ctx2, self.ctx
-        try:
-            with torch.cuda.stream(self.side_stream):
-                yield
-                done = torch.cuda.Event()
-                done.record()
-        finally:
-            self.ctx, self.ctx2 = self.ctx2, self.ctx
-        self._side_done = done
+        return ev
 
-    def join_side(self):
-        if self._side_done is not None:
-            torch.cuda.current_stream().wait_event(self._side_done)
-            self._side_done = None
+    @staticmethod
+    def after(ev):
+        """The current lane continues only once `ev` (mark() of any lane) has happened."""
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _run(self, ops, overlap=False):
         """Run a layer program (overlap: its wgrad launches go to the side stream, see __init__).  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
@@ -868,10 +879,10 @@ class FasterRCNNEngine:
         class code (-1 = dropped).  Returns (plan, cls host int32 [n], n)."""
         return self.roi_targets_finish(self.roi_targets_launch(R_dev, n_dev, gt, width, height, rw, rh, n_max))
 
-    def roi_targets_launch(self, R_dev, n_dev, gt, width, height, rw, rh, n_max=300):
-        """Device half of roi_targets + asynchronous copy of the class codes to pinned memory."""
+    def roi_targets_launch(self, R_dev, n_dev, gt, width, height, rw, rh, n_max=300, slot=0):
+        """Device half of roi_targets + asynchronous copy of the class codes to pinned memory (`slot`: buffer set)."""
         dev = self.dev
-        key = ("rtgt",)
+        key = ("rtgt", slot)
         if key not in self._plans:
             self._plans[key] = dict(keep=torch.zeros(1024, dtype=torch.uint8, device=dev), cls=torch.zeros(1024, dtype=torch.int32, device=dev),
                                     box=torch.zeros(1024, 4, dtype=torch.int32, device=dev), t=torch.zeros(1024, 4, dtype=torch.float64, device=dev),

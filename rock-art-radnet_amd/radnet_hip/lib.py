@@ -71,6 +71,7 @@ def load_library():
         "radnet_set_autotune": (C.c_int, [vp, C.c_int]),
         "radnet_tuned_shapes": (C.c_int, [vp]),
         "radnet_tune_save": (C.c_int, [vp, C.c_char_p]),
+        "radnet_share_tuning": (C.c_int, [vp, vp]),
         "radnet_tune_load": (C.c_int, [vp, C.c_char_p]),
         "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "radnet_force_waves": (C.c_int, [vp, C.c_int]),

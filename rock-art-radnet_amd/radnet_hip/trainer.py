@@ -13,6 +13,7 @@ Batch semantics (the reference is batch-1 only): every image is an independent r
 gradient is the mean over all images of all ranks (SURVEY.md 8d cfg 4).  The order of draws from NumPy's
 global RNG is the reference's: subsampling of image 0..B-1, then sample selection of image 0..B-1.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -50,6 +51,7 @@ def allreduce_grad_arena_start(flat, world, group=None):
 
 
 class TrainStep:
+    NBUF = 3        # buffer sets in rotation: batch i+1's forward passes may not wait for batch i-1's head phase
 
     def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
         """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
@@ -63,17 +65,19 @@ class TrainStep:
         self.group = dist_group
         self.defer_head_update = (world_size > 1) if defer_head_update is None else bool(defer_head_update)
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
-        self._pre = None                 # phases A/B of the next batch, enqueued ahead (step(next_batch=...))
-        self._parity = 0                 # buffer set the next _launch_ab uses
-        # the prefetched phases A/B run on the engine's side stream, concurrently with this step's head phase
-        self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "on_side_stream")
+        self._head_done = {}             # buffer set -> event: end of the head phase that last read its feature map
+        self._head_last = None           # event: end of the last head phase enqueued on the head lane
+        self._pre = None                 # state of the next batch, enqueued ahead (step(next_batch=...))
+        self._slots = 0                  # batches started: buffer set = count % NBUF
+        # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
+        self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "lane")
         self.skipped_head_steps = 0
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
         self.host_marks = None      # set to [] to record (label, perf_counter) at the host-side phase boundaries
         dev = eng.dev
-        self._rpn_l = torch.zeros(64, 2, dtype=torch.float32, device=dev)     # per-image loss slots (logging)
-        self._det_l = torch.zeros(64, 3, dtype=torch.float32, device=dev)
+        self._rpn_l = torch.zeros(self.NBUF, 64, 2, dtype=torch.float32, device=dev)     # per-image loss slots (logging)
+        self._det_l = torch.zeros(self.NBUF, 64, 3, dtype=torch.float32, device=dev)
 
     def _allreduce(self, arena):
         allreduce_grad_arena(arena.g, self.world, self.group)
@@ -89,7 +93,11 @@ class TrainStep:
         self.eng.refresh_head_shift()
 
     def flush(self):
-        """Apply a head update still in flight (deferred mode); no-op otherwise."""
+        """End of a pipelined run: the main stream waits for the head lane, and a head update still in flight
+        (deferred mode) is applied."""
+        if self._head_last is not None:
+            self.eng.after(self._head_last)
+            self._head_last = None
         self._finish_head_update()
 
     def _gt(self, s):
@@ -102,38 +110,76 @@ class TrainStep:
             s["_gt_dev"] = self.eng.upload_gt(boxes, isbg, cls)
         return s["_gt_dev"]
 
-    def _launch_a(self, batch, parity):
+    def _next_slot(self):
+        self._slots += 1
+        return (self._slots - 1) % self.NBUF
+
+    def _launch_a(self, batch, slot):
         """Device half of phase A (anchor labelling + async copy of the label maps) and the weight-independent part of
-        phase B (upload, frozen base forward) of every image of `batch`, into the buffer set `parity`."""
+        phase B (upload, frozen base forward) of every image of `batch`, into buffer set `slot`."""
         eng = self.eng
         nloc = len(batch)
         tp, plans = [], []
         for i, s in enumerate(batch):
             H, W = s["img"].shape[:2]
-            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=parity * nloc + i))
+            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=slot * nloc + i))
         for i, s in enumerate(batch):
-            bp = eng.upload_image(s["img"], slot=parity * nloc + i)
+            bp = eng.upload_image(s["img"], slot=slot * nloc + i)
             eng.base_forward(bp)
             plans.append(bp)
-        return dict(batch=batch, tp=tp, plans=plans, rps=None, parity=parity)
+        return dict(batch=batch, tp=tp, plans=plans, rps=None, slot=slot)
 
     def _launch_b(self, st):
         """RPN forward of every image of a batch whose base forward is enqueued: reads the RPN weights."""
         st["rps"] = [self.eng.rpn_forward(bp) for bp in st["plans"]]
         return st
 
-    def _launch_ab(self, batch, parity):
-        return self._launch_b(self._launch_a(batch, parity))
+    def _launch_ab(self, batch, slot):
+        return self._launch_b(self._launch_a(batch, slot))
+
+    def _rpn_phase(self, st, ntot, mark):
+        """Phases A (host half) + C + the device part of D for a batch whose forward passes are enqueued: label maps
+        subsampled on the host RNG, RPN losses + backward over the local images, [all-reduce], Adam #1, re-prediction with
+        the updated weights, proposals, RoI labelling (async copy of the class codes)."""
+        eng = self.eng
+        C = eng.C
+        batch, plans, rps, slot = st["batch"], st["plans"], st["rps"], st["slot"]
+        nloc = len(batch)
+        # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
+        for i in range(nloc):
+            ycls, yregr, _ = eng.anchor_targets_finish(st["tp"][i])
+            mark("A: label maps on host, subsampled, packed")
+            eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
+            eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[slot][i])
+        self._allreduce(eng.rpn_arena)
+        eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
+        st["adam1"] = eng.mark() if hasattr(eng, "mark") else None
+        mark("C: rpn backward + adam enqueued")
+        st["roi"] = []
+        for i, bp in enumerate(plans):
+            s = batch[i]
+            eng._run(rps[i]["fwd"])
+            R, Rn = eng.proposals(rps[i], overlap_thresh=0.7, max_boxes=300)
+            rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
+            st["roi"].append((R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i)))
+        mark("D: rpn re-predict + proposals + roi targets enqueued")
 
     def step(self, batch, next_batch=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
         width, height: source-frame size the boxes refer to}.  Losses of the step: self.losses().
 
-        next_batch (optional, what a prefetching data loader knows): its phases A/B are ENQUEUED while this step waits
-        for the RoI class codes -- the one point where the host must drain the GPU (sample selection runs on NumPy's
-        RNG).  They read only the frozen base and the RPN weights, which nothing after this step's Adam #1 changes, so
-        the arithmetic and the order of RNG draws are exactly those of back-to-back steps; the GPU just never idles
-        while the host selects samples and builds the head batch.  The next call must pass that same object."""
+        next_batch (optional, what a prefetching data loader knows) switches the PIPELINED mode on; the next call must
+        pass that same object as `batch`, and flush() ends the run.  Three chains then share the GPU, each on its own
+        stream and context (engine lanes), working on three consecutive batches:
+          side: labelling kernels, upload and frozen base forward of the NEXT batch, its RPN forward after Adam #1
+          main: RPN backward, Adam #1, re-prediction, proposals and RoI labelling -- of the next batch as soon as this
+                batch's RoI class codes have reached the host
+          head: RoI batch, classifier forward / backward, Adam #2 of THIS batch
+        They touch disjoint trainable weights (the base is frozen, the RPN and the classifier have their own optimizers),
+        so every value is computed from exactly the operands the one-after-the-other order would use; no GEMM of this
+        network fills 256 CUs for its whole duration (tails, split-K reductions, the one-workgroup NMS), co-scheduled
+        chains fill those holes.  The host's order -- sample selection of this batch, then subsampling of the next
+        batch's anchors -- and with it the order of draws from NumPy's global RNG is the reference's."""
         eng = self.eng
         C = eng.C
         nloc = len(batch)
@@ -146,83 +192,86 @@ class TrainStep:
                 marks.append((label, time.perf_counter()))
 
         mark("start")
-        # ---- phase A (device half) + phase B, all asynchronous -- unless the previous step already enqueued them
-        if self._pre is not None and self._pre["batch"] is batch:
-            st = self._pre
-        else:
-            st = self._launch_ab(batch, self._parity)
+        after = getattr(eng, "after", lambda ev: None)
+        pipelined = self.side_prefetch and next_batch is not None and not eng.ctx.timing_on
+        st = self._pre if self._pre is not None and self._pre["batch"] is batch else None
         self._pre = None
-        if self.side_prefetch:
-            eng.join_side()
-        self._parity = st["parity"] ^ 1
-        tp, plans, rps = st["tp"], st["plans"], st["rps"]
-        # side-stream prefetch: the next batch's labelling kernels and frozen base forward need nothing from this step,
-        # so they start now, beside this step's RPN backward / proposal / head phases; its RPN forward follows Adam #1
-        early = self.side_prefetch and next_batch is not None and not eng.ctx.timing_on
-        if early:
-            with eng.on_side_stream():
-                self._pre = self._launch_a(next_batch, self._parity)
-        mark("B: upload + base + rpn forward enqueued")
-        # ---- phase A (host half, overlapped with B) + phase C
-        # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
+        if st is None:
+            st = self._launch_ab(batch, self._next_slot())
+        after(st.get("done"))                          # main lane: forward passes enqueued on the side lane
+        if "roi" not in st:                            # first step of a run, or the previous call was not pipelined
+            self._rpn_phase(st, ntot, mark)
+        nxt = None
+        if pipelined:
+            slot = self._next_slot()
+            with eng.lane("side"):
+                after(self._head_done.get(slot))       # the head phase that last read this buffer set's feature map
+                nxt = self._launch_a(next_batch, slot)
+                after(st["adam1"])                     # its RPN forward reads the RPN weights Adam #1 of this batch wrote
+                self._launch_b(nxt)
+                nxt["done"] = eng.mark()
+        else:
+            after(self._head_last)                     # the head phase below runs on the main lane
+            if next_batch is not None:
+                nxt = self._launch_ab(next_batch, self._next_slot())  # one lane: keeps the GPU busy across the sync below
+        mark("B: next batch's upload + base + rpn forward enqueued")
+        # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
+        picks = []
         for i in range(nloc):
-            ycls, yregr, _ = eng.anchor_targets_finish(tp[i])
-            mark("A: label maps on host, subsampled, packed")
-            eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
-            eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[i])
-        self._allreduce(eng.rpn_arena)
-        eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
-        if early:
-            with eng.on_side_stream():
-                self._launch_b(self._pre)
-        mark("C: rpn backward + adam enqueued")
-        # ---- phase D: re-predict with updated weights, propose, label, sample, head train
-        n_head = 0
-        for i, bp in enumerate(plans):
-            s = batch[i]
-            rp = rps[i]
-            eng._run(rp["fwd"])
-            R, Rn = eng.proposals(rp, overlap_thresh=0.7, max_boxes=300)
-            rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
-            P = eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)
-            if next_batch is not None and i == nloc - 1 and not early:
-                self._pre = self._launch_ab(next_batch, self._parity)      # keeps the GPU busy across the sync below
-            mark("D: rpn re-predict + proposals + roi targets enqueued")
-            P, cls, n = eng.roi_targets_finish(P)                             # the step's one host sync in this phase
+            R, P = st["roi"][i]
+            P, cls, n = eng.roi_targets_finish(P)
             mark("D: roi classes on host")
             kept = np.nonzero(cls >= 0)[0]
             if n <= 0 or len(kept) == 0:                           # calc_iou -> None: the reference skips the head step
                 self.skipped_head_steps += 1
+                picks.append(None)
                 continue
             sel_k, _ = E.select_samples(cls[kept], eng.bg, C.n_rois)
-            sel = kept[np.asarray(sel_k, dtype=np.int64)]
+            picks.append((P, kept[np.asarray(sel_k, dtype=np.int64)]))
             mark("D: samples selected")
             if self.capture is not None:
-                self.capture.append(dict(pred=rp["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(), keep=(cls >= 0).copy(),
-                                         cls=cls.copy(), sel_kept=list(sel_k)))
-            hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
-            eng.pack_roi_batch(P, sel, hp)
-            self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
-            eng.head_forward(hp, training=True)
-            eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
-            eng.head_backward(hp, accumulate=True, loss_out=self._det_l[n_head])
-            n_head += 1
-        if n_head > 0 or self.world > 1:
-            self._finish_head_update()               # only still pending when every local image skipped its head phase
-            if self.defer_head_update:
-                self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group), ntot)
-            else:
-                self._allreduce(eng.head_arena)
-                eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
-                eng.refresh_head_shift()
+                self.capture.append(dict(pred=st["rps"][i]["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(),
+                                         keep=(cls >= 0).copy(), cls=cls.copy(), sel_kept=list(sel_k)))
+        # ---- pipelined: the next batch's RPN phase goes first -- the host sync of the NEXT call waits for it
+        if pipelined:
+            after(nxt["done"])
+            self._rpn_phase(nxt, ntot, mark)
+        # ---- phase D, device half: classifier train step
+        head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
+        slot = st["slot"]
+        n_head = 0
+        with head_lane():      # what it reads from the other lanes (feature map, RoI labels) is complete: the host waited
+            for i, bp in enumerate(st["plans"]):
+                if picks[i] is None:
+                    continue
+                hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
+                eng.pack_roi_batch(picks[i][0], picks[i][1], hp)
+                self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
+                eng.head_forward(hp, training=True)
+                eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
+                eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head])
+                n_head += 1
+            if n_head > 0 or self.world > 1:
+                self._finish_head_update()               # only still pending when every local image skipped its head phase
+                if self.defer_head_update:
+                    self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group), ntot)
+                else:
+                    self._allreduce(eng.head_arena)
+                    eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
+                    eng.refresh_head_shift()
+            if pipelined:
+                self._head_last = self._head_done[slot] = eng.mark()
         mark("D: head forward + backward + adam enqueued")
-        self.last = (nloc, n_head)
+        self._pre = nxt
+        self.last = (nloc, n_head, slot)
         return self
 
     def losses(self):
         """Host copy of the last step's mean losses (one device sync)."""
-        nloc, n_head = self.last
-        r = self._rpn_l[:nloc].cpu().numpy().mean(0)
-        d = self._det_l[:max(n_head, 1)].cpu().numpy().mean(0) if n_head else np.zeros(3, np.float32)
+        nloc, n_head, slot = self.last
+        if self._head_last is not None:
+            self._head_last.synchronize()            # the head lane wrote the detector losses
+        r = self._rpn_l[slot][:nloc].cpu().numpy().mean(0)
+        d = self._det_l[slot][:max(n_head, 1)].cpu().numpy().mean(0) if n_head else np.zeros(3, np.float32)
         return {"rpn_cls": float(r[0]), "rpn_regr": float(r[1]), "det_cls": float(d[0]), "det_regr": float(d[1]), "det_acc": float(d[2]),
                 "n_head": n_head}

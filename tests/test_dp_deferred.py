@@ -85,7 +85,7 @@ class FakeEngine:
     def proposals(self, rp, overlap_thresh=0.7, max_boxes=300):
         return None, None
 
-    def roi_targets_launch(self, R, Rn, gt, width, height, rw, rh):
+    def roi_targets_launch(self, R, Rn, gt, width, height, rw, rh, slot=0):
         return dict()
 
     @staticmethod

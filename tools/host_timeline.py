@@ -23,8 +23,9 @@ def main():
     eng.set_weights(synth.synthetic_weights(seed=3))
     ts = TrainStep(eng)
     batch = bench.make_batch(0, 1, 600, 1000)
-    for _ in range(5):
-        ts.step(batch)
+    pipelined = os.environ.get("RADNET_TIMELINE_SERIAL", "0") != "1"       # as bench.py runs it: next batch announced
+    for _ in range(8):
+        ts.step(batch, next_batch=batch if pipelined else None)
     torch.cuda.synchronize()
     acc = collections.OrderedDict()
     # split the label-map phase: time inside the host subsampling itself
@@ -51,10 +52,11 @@ def main():
     t_all = time.perf_counter()
     for _ in range(steps):
         ts.host_marks = []
-        ts.step(batch)
+        ts.step(batch, next_batch=batch if pipelined else None)
         m = ts.host_marks
         for (l0, t0), (l1, t1) in zip(m[:-1], m[1:]):
             acc[l1] = acc.get(l1, 0.0) + (t1 - t0)
+    ts.flush()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t_all) / steps
     print("step wall %.0f us (host thread, %d steps)" % (wall * 1e6, steps))
