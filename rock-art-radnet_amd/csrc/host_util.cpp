@@ -11,13 +11,9 @@
 //
 // Exactness: cumsum is the same strictly sequential chain of fp64 adds, the normalisation the same IEEE
 // division, and searchsorted(side='right') is order-defined (first idx with cdf[idx] > x) whatever the search
-// strategy -- here a 4096-bucket jump table + short scan instead of a cold binary search.
+// strategy -- here an interpolation guess + short walk instead of a cold binary search.
 #include <stdint.h>
 #include <string.h>
-
-namespace {
-constexpr int kBuckets = 4096;
-}
 
 extern "C" int64_t radnet_host_choice_round(double* live_p, int64_t* live_idx, int64_t* n_live_io, int64_t* found, int64_t n_found,
                                             const double* x, int64_t k, double* cdf, uint8_t* sel) {
@@ -33,31 +29,48 @@ extern "C" int64_t radnet_host_choice_round(double* live_p, int64_t* live_idx, i
   }
   const double total = cdf[n - 1];
   for (int64_t i = 0; i < n; ++i) cdf[i] /= total;                  // cdf /= cdf[-1]  (vectorises: vdivpd)
-  // jump table: start[b] = first live position with cdf > b / kBuckets
-  static thread_local int64_t start[kBuckets + 1];
-  {
-    int64_t idx = 0;
-    for (int b = 0; b <= kBuckets; ++b) {
-      const double edge = (double)b / (double)kBuckets;
-      while (idx < n && !(cdf[idx] > edge)) ++idx;
-      start[b] = idx;
-    }
-  }
+  // searchsorted(side='right') = first position with cdf > x, whatever the search strategy.  The probabilities here are
+  // (near-)uniform over the live entries (utils.py:789-795: p = (count/n)/count per channel), so cdf[i] ~ (i+1)/n and
+  // position floor(x*n) is the answer or its neighbour: start there and walk to the exact boundary; a walk that gets long
+  // (a strongly non-uniform p) falls back to bisection of the remaining range.  One predictable compare per draw instead of
+  // a cold binary search (NumPy) or a bucket scan.
   memset(sel, 0, (size_t)n);
   int64_t added = 0;
+  const double dn = (double)n;
   for (int64_t j = 0; j < k; ++j) {
     const double v = x[j];                                          // in [0, 1)
-    int b = (int)(v * (double)kBuckets);                            // exact: power-of-two scaling
-    if (b < 0) b = 0;
-    if (b >= kBuckets) b = kBuckets - 1;
-    int64_t idx = start[b];                                         // first position with cdf > b/B  (<= answer)
-    while (idx < n && !(cdf[idx] > v)) ++idx;                       // searchsorted(side='right'): first cdf > x
-    if (idx >= n) idx = n - 1;                                      // unreachable for x < 1
-    if (!sel[idx]) {                                                // np.unique(return_index) + sort = first occurrences, in order
-      sel[idx] = 1;
-      found[n_found + added] = live_idx[idx];
-      ++added;
+    int64_t idx = (int64_t)(v * dn);
+    if (idx >= n) idx = n - 1;
+    if (cdf[idx] > v) {                                             // answer <= idx: walk down while the left neighbour also exceeds v
+      int steps = 0;
+      while (idx > 0 && cdf[idx - 1] > v) {
+        --idx;
+        if (++steps == 8) {                                         // bisect [0, idx]: first position with cdf > v
+          int64_t lo = 0, hi = idx;
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cdf[mid] > v) hi = mid; else lo = mid + 1; }
+          idx = lo;
+          break;
+        }
+      }
+    } else {                                                        // answer > idx
+      int steps = 0;
+      ++idx;
+      while (idx < n && !(cdf[idx] > v)) {
+        ++idx;
+        if (++steps == 8) {
+          int64_t lo = idx, hi = n;                                 // first position in [idx, n) with cdf > v (n if none)
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cdf[mid] > v) hi = mid; else lo = mid + 1; }
+          idx = lo;
+          break;
+        }
+      }
+      if (idx >= n) idx = n - 1;                                    // unreachable for x < 1 (cdf[n-1] == 1.0)
     }
+    // np.unique(return_index) + sort = first occurrences, in draw order.  Branch-free (a repeat overwrites the next free
+    // slot and does not advance): `found` holds one element more than can ever be found.
+    found[n_found + added] = live_idx[idx];
+    added += sel[idx] ^ 1;
+    sel[idx] = 1;
   }
   int64_t w = 0;                                                    // p[found] = 0  ==  drop them from the live lists
   for (int64_t i = 0; i < n; ++i) {

@@ -921,14 +921,15 @@ def _uniform_table_probs(chan_of_item, neg_chans, n_total):
     """The reference builds p[i] = (count[ch_i] / n) / count[ch_i] from the NEGATIVES' channel histogram
     (utils.py:789-795, 804-810) and raises KeyError for a channel without negatives.  Vectorised: the same IEEE
     operations element-wise, hence the same p and the same draws."""
-    chans, counts = np.unique(neg_chans, return_counts=True)
-    idx = np.searchsorted(chans, chan_of_item)
-    idx_c = np.minimum(idx, len(chans) - 1) if len(chans) else idx
-    bad = (idx >= len(chans)) | (chans[idx_c] != chan_of_item) if len(chans) else np.ones(len(chan_of_item), bool)
-    if bad.any():
-        raise KeyError(int(chan_of_item[np.argmax(bad)]))
-    cnt = counts[idx_c]
-    return (cnt / n_total) / cnt
+    counts = np.bincount(neg_chans, minlength=int(chan_of_item.max()) + 1 if len(chan_of_item) else 1)
+    if (counts == 0).any():
+        bad = counts[chan_of_item] == 0
+        if bad.any():
+            raise KeyError(int(chan_of_item[np.argmax(bad)]))
+    per_chan = np.zeros(counts.shape[0], dtype=np.float64)       # p depends on the item's channel only: same two divisions
+    nz = counts > 0
+    per_chan[nz] = (counts[nz] / n_total) / counts[nz]
+    return per_chan[chan_of_item]
 
 
 def choice_without_replacement(n, size, p):
@@ -944,17 +945,19 @@ def choice_without_replacement(n, size, p):
         raise ValueError("Cannot take a larger sample than population when 'replace=False'")
     if np.count_nonzero(p > 0) < size:
         raise ValueError("Fewer non-zero entries in p than size")
-    found = np.zeros(max(size, 1), dtype=np.int64)
+    found = np.zeros(size + 1, dtype=np.int64)               # + 1: the helper's branch-free append writes one slot ahead
     live_idx = np.flatnonzero(p > 0).astype(np.int64)        # zero entries only ever add 0.0 to NumPy's cumsum
     live_p = np.ascontiguousarray(p[live_idx])
     n_live = np.array([live_idx.shape[0]], dtype=np.int64)
     cdf = np.empty(n, dtype=np.float64)
     sel = np.empty(n, dtype=np.uint8)
     n_uniq = 0
+    # raw addresses once: ndarray.ctypes builds a helper object per access (~3 us each, x7 per round)
+    a_p, a_idx, a_n, a_found, a_cdf, a_sel = (v.__array_interface__["data"][0] for v in (live_p, live_idx, n_live, found, cdf, sel))
+    fn = lib.radnet_host_choice_round
     while n_uniq < size:
         x = np.random.random_sample(size - n_uniq)
-        n_uniq += int(lib.radnet_host_choice_round(live_p.ctypes.data, live_idx.ctypes.data, n_live.ctypes.data, found.ctypes.data, n_uniq,
-                                                   x.ctypes.data, x.shape[0], cdf.ctypes.data, sel.ctypes.data))
+        n_uniq += int(fn(a_p, a_idx, a_n, a_found, n_uniq, x.__array_interface__["data"][0], x.shape[0], a_cdf, a_sel))
     return found[:size]
 
 
@@ -963,19 +966,25 @@ def subsample_valid(valid, overlap, max_regions=256):
     negatives on the *global NumPy RNG stream*, which is part of the reference's contract (train.py:41,134).
     valid / overlap: uint8 [A][fh][fw] (the NCHW order np.where enumerates in the reference); `valid` is
     edited in place.  Returns n_pos."""
-    pos = np.where((overlap == 1) & (valid == 1))
-    neg = np.where((overlap == 0) & (valid == 1))
-    n_pos, n_neg = len(pos[0]), len(neg[0])
+    if not (valid.flags.c_contiguous and overlap.flags.c_contiguous):
+        raise ValueError("subsample_valid: label maps must be C-contiguous")
+    vf, of = valid.reshape(-1), overlap.reshape(-1)      # flat C order == the order np.where enumerates (a, y, x) in
+    hw = valid.shape[1] * valid.shape[2]
+    live = vf == 1
+    pos = np.flatnonzero(live & (of == 1))
+    neg = np.flatnonzero(live & (of == 0))
+    n_pos, n_neg = len(pos), len(neg)
+    neg_ch = neg // hw
     half = int(max_regions / 2)
     if n_pos > max_regions / 2:
-        p = _uniform_table_probs(pos[0], neg[0], n_pos)
+        p = _uniform_table_probs(pos // hw, neg_ch, n_pos)
         off = choice_without_replacement(n_pos, n_pos - half, p)
-        valid[pos[0][off], pos[1][off], pos[2][off]] = 0
+        vf[pos[off]] = 0
         n_pos = half
     if n_neg + n_pos > max_regions:
-        p = _uniform_table_probs(neg[0], neg[0], n_neg)
+        p = _uniform_table_probs(neg_ch, neg_ch, n_neg)
         off = choice_without_replacement(n_neg, n_neg - n_pos, p)
-        valid[neg[0][off], neg[1][off], neg[2][off]] = 0
+        vf[neg[off]] = 0
     return n_pos
 
 
