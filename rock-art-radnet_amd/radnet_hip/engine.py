@@ -144,6 +144,10 @@ class FasterRCNNEngine:
         self.ws3 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
         self.ctx3.check(self.lib.radnet_set_workspace(self.ctx3.h, self.ws3.data_ptr(), self.ws3.numel()), "set_workspace")
         self._lanes = {"side": (self.ctx2, self.side_stream), "head": (self.ctx3, self.head_stream)}
+        if os.environ.get("RADNET_FORCE_CONFIG"):      # experiment: "tile_a,tile_b,slices" for every GEMM launch of every lane
+            fa, fb, fs = (int(v) for v in os.environ["RADNET_FORCE_CONFIG"].split(","))
+            for c in (self.ctx, self.ctx2, self.ctx3):
+                c.check(self.lib.radnet_force_config(c.h, fa, fb, fs), "force_config")
         for c in (self.ctx2, self.ctx3):           # one table of measured launch choices for all lanes
             self.ctx.check(self.lib.radnet_share_tuning(c.h, self.ctx.h), "share_tuning")
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]

@@ -13,6 +13,7 @@ Batch semantics (the reference is batch-1 only): every image is an independent r
 gradient is the mean over all images of all ranks (SURVEY.md 8d cfg 4).  The order of draws from NumPy's
 global RNG is the reference's: subsampling of image 0..B-1, then sample selection of image 0..B-1.
 """
+import collections
 import contextlib
 import os
 
@@ -51,7 +52,7 @@ def allreduce_grad_arena_start(flat, world, group=None):
 
 
 class TrainStep:
-    NBUF = 3        # buffer sets in rotation: batch i+1's forward passes may not wait for batch i-1's head phase
+    NBUF = 4        # buffer sets in rotation: batch i+2's forward passes must not wait for batch i-1's head phase
 
     def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
         """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
@@ -67,7 +68,7 @@ class TrainStep:
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self._head_done = {}             # buffer set -> event: end of the head phase that last read its feature map
         self._head_last = None           # event: end of the last head phase enqueued on the head lane
-        self._pre = None                 # state of the next batch, enqueued ahead (step(next_batch=...))
+        self._queue = collections.deque()    # states of the announced batches, enqueued ahead (step(next_batch=...))
         self._slots = 0                  # batches started: buffer set = count % NBUF
         # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
         self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "lane")
@@ -164,22 +165,25 @@ class TrainStep:
             st["roi"].append((R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i)))
         mark("D: rpn re-predict + proposals + roi targets enqueued")
 
-    def step(self, batch, next_batch=None):
+    def step(self, batch, next_batch=None, after_next=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
         width, height: source-frame size the boxes refer to}.  Losses of the step: self.losses().
 
-        next_batch (optional, what a prefetching data loader knows) switches the PIPELINED mode on; the next call must
-        pass that same object as `batch`, and flush() ends the run.  Three chains then share the GPU, each on its own
-        stream and context (engine lanes), working on three consecutive batches:
-          side: labelling kernels, upload and frozen base forward of the NEXT batch, its RPN forward after Adam #1
-          main: RPN backward, Adam #1, re-prediction, proposals and RoI labelling -- of the next batch as soon as this
-                batch's RoI class codes have reached the host
-          head: RoI batch, classifier forward / backward, Adam #2 of THIS batch
+        next_batch / after_next (optional, what a prefetching data loader knows: the batches of the next two calls, which
+        must then pass these same objects) switch the PIPELINED mode on; flush() ends the run.  Three chains then share
+        the GPU, each on its own stream and context (engine lanes), working on consecutive batches:
+          side: labelling kernels, upload and frozen base forward of batch i+2 (i+1 without after_next), its RPN forward
+                once Adam #1 of the batch before it is enqueued
+          main: RPN backward, Adam #1, re-prediction, proposals and RoI labelling of batch i+1, as soon as batch i's RoI
+                class codes have reached the host
+          head: RoI batch, classifier forward / backward, Adam #2 of batch i
         They touch disjoint trainable weights (the base is frozen, the RPN and the classifier have their own optimizers),
         so every value is computed from exactly the operands the one-after-the-other order would use; no GEMM of this
         network fills 256 CUs for its whole duration (tails, split-K reductions, the one-workgroup NMS), co-scheduled
-        chains fill those holes.  The host's order -- sample selection of this batch, then subsampling of the next
-        batch's anchors -- and with it the order of draws from NumPy's global RNG is the reference's."""
+        chains fill those holes.  With after_next the base forward of a batch is enqueued a whole step before its RPN
+        phase needs it, so the host's one wait per step covers the RPN chain alone.  The host's order -- sample selection
+        of this batch, then subsampling of the next batch's anchors -- and with it the order of draws from NumPy's global
+        RNG is the reference's."""
         eng = self.eng
         C = eng.C
         nloc = len(batch)
@@ -194,26 +198,41 @@ class TrainStep:
         mark("start")
         after = getattr(eng, "after", lambda ev: None)
         pipelined = self.side_prefetch and next_batch is not None and not eng.ctx.timing_on
-        st = self._pre if self._pre is not None and self._pre["batch"] is batch else None
-        self._pre = None
+        q = self._queue                                # states of the coming batches, in call order
+        st = q.popleft() if q and q[0]["batch"] is batch else None
         if st is None:
+            q.clear()                                  # not the announced batch: what was prepared is dropped
             st = self._launch_ab(batch, self._next_slot())
         after(st.get("done"))                          # main lane: forward passes enqueued on the side lane
         if "roi" not in st:                            # first step of a run, or the previous call was not pipelined
             self._rpn_phase(st, ntot, mark)
-        nxt = None
+        if q and q[0]["batch"] is not next_batch:
+            q.clear()
+        nxt = q[0] if q else None
+        if len(q) > 1 and q[1]["batch"] is not after_next:
+            q.pop()
+        late = None                                    # state whose RPN forward waits for Adam #1 of `nxt`
         if pipelined:
-            slot = self._next_slot()
-            with eng.lane("side"):
+            def side_a(b):
+                slot = self._next_slot()
                 after(self._head_done.get(slot))       # the head phase that last read this buffer set's feature map
-                nxt = self._launch_a(next_batch, slot)
-                after(st["adam1"])                     # its RPN forward reads the RPN weights Adam #1 of this batch wrote
-                self._launch_b(nxt)
-                nxt["done"] = eng.mark()
+                return self._launch_a(b, slot)
+
+            with eng.lane("side"):
+                if nxt is None:                        # start-up: nothing of the next batch is enqueued yet
+                    nxt = side_a(next_batch)
+                    after(st["adam1"])                 # its RPN forward reads the RPN weights Adam #1 of this batch wrote
+                    self._launch_b(nxt)
+                    nxt["done"] = eng.mark()
+                    q.append(nxt)
+                if after_next is not None and len(q) < 2:
+                    late = side_a(after_next)
+                    q.append(late)
         else:
             after(self._head_last)                     # the head phase below runs on the main lane
-            if next_batch is not None:
+            if next_batch is not None and nxt is None:
                 nxt = self._launch_ab(next_batch, self._next_slot())  # one lane: keeps the GPU busy across the sync below
+                q.append(nxt)
         mark("B: next batch's upload + base + rpn forward enqueued")
         # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
         picks = []
@@ -236,6 +255,11 @@ class TrainStep:
         if pipelined:
             after(nxt["done"])
             self._rpn_phase(nxt, ntot, mark)
+            if late is not None:
+                with eng.lane("side"):
+                    after(nxt["adam1"])
+                    self._launch_b(late)
+                    late["done"] = eng.mark()
         # ---- phase D, device half: classifier train step
         head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
         slot = st["slot"]
@@ -262,7 +286,6 @@ class TrainStep:
             if pipelined:
                 self._head_last = self._head_done[slot] = eng.mark()
         mark("D: head forward + backward + adam enqueued")
-        self._pre = nxt
         self.last = (nloc, n_head, slot)
         return self
 
