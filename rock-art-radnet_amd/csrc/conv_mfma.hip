@@ -93,6 +93,12 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
   f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// voffset (per lane) + soffset (wave-uniform, an SGPR): the hardware adds them and range-checks the SUM without 32-bit
+// wrap-around (tools/soffset_probe.hip: kOOB in either operand reads 0), so the uniform part of an address costs no VALU
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int2 buf_load2i(__amdgpu_buffer_rsrc_t r, unsigned off) {
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
@@ -302,9 +308,31 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     a_base[i] = ((img * g.H + (oh * g.stride - g.pad_t)) * g.W + a_iw0[i]) * a_cbytes;
   }
 
+  // Channel-tiled layers (!SMALLC): everything that changes from K tile to K tile is wave-uniform -- the tap (kh, kw), the
+  // first channel, the weight row -- and travels in the load's SGPR offset; what is left per lane is a constant offset and
+  // ONE bit per tap ("this tap of this output row falls into the padding"), folded into bit 31 of the offset.  The
+  // descriptor of x starts a_bias bytes early so that the per-lane part of a halo row is never negative.
+  const unsigned a_bias = SMALLC ? 0u : (unsigned)((g.pad_t * g.W + g.pad_l) * g.C * 4);
+  unsigned a_voff[A_ITERS], a_inv[A_ITERS];
+  if (!SMALLC) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const bool row_ok = a_ih0[i] > -(1 << 23);
+      unsigned inv = 0u;
+      for (int p = 0, kh = 0, kw = 0; p < g.npos; ++p) {
+        const bool ok = ((unsigned)(a_ih0[i] + kh) < (unsigned)g.H) & ((unsigned)(a_iw0[i] + kw) < (unsigned)g.W);
+        inv |= (ok ? 0u : 1u) << p;
+        if (++kw == g.KW) { kw = 0; ++kh; }
+      }
+      a_voff[i] = row_ok ? (unsigned)(a_base[i] + (int)a_bias + a_kc * 16) : 0u;
+      a_inv[i] = row_ok ? inv : ~0u;
+    }
+  }
+
   // forward weights: byte offset of this thread's chunk (row kr, column n) in K tile 0; a tile adds BK rows
   int b_base[B_ITERS];
   bool b_nvalid[B_ITERS];
+  unsigned b_voff[B_ITERS];
   const int b_tile_bytes = BK * g.ldw * 4;
   if (BMODE == 0) {
     constexpr int CPR = BN / 4;
@@ -314,6 +342,13 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
       const int kr = c / CPR, n = n0 + (c - kr * CPR) * 4;
       b_base[i] = (kr * g.ldw + n) * 4;
       b_nvalid[i] = n < g.N;
+      b_voff[i] = b_nvalid[i] ? (unsigned)b_base[i] : kOOB;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {       // dgrad: row n of w^T (forward input channel), this thread's 4 channels
+      const int n = n0 + (tid >> 3) + kRowStep * i;
+      b_voff[i] = n < g.N ? ((unsigned)n * (unsigned)g.ldw + (unsigned)a_kc * 4u) * 4u : kOOB;
     }
   }
 
@@ -333,7 +368,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
 
   // batched launch (radnet_gemm_batched): problem blockIdx.z of a strided batch, same geometry
   const long long bz = g.batch > 1 ? (long long)blockIdx.z : 0;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x + bz * g.x_bstride, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(g.x + bz * g.x_bstride) - a_bias, g.x_bytes ? g.x_bytes + a_bias : 0u);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w + bz * g.w_bstride, g.w_bytes);
   const bool has_in_scale = g.in_scale != nullptr;
   const __amdgpu_buffer_rsrc_t rscale = make_rsrc(g.in_scale, has_in_scale ? (unsigned)g.C * 4u : 0u);
@@ -355,6 +390,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   // state of the tile being loaded (tile_begin -> load_op)
   int t_kt = 0, t_ci = 0, t_kh = 0, t_kw = 0, t_fpos = 0, t_aoff = 0;
   bool t_live = false, t_kv = false;
+  unsigned s_a = kOOB, s_b = kOOB, s_sh = 0;       // wave-uniform: SGPR offsets of the tile's A / B loads, tap -> bit-31 shift
 
   auto tile_begin = [&](int kt, bool live, Stage& st) {
     t_kt = kt;
@@ -366,15 +402,15 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
       t_kv = live & (p < g.npos);
       t_aoff = (t_kh * g.W + t_kw) * 16;
     } else {
-      t_ci = ci0 + a_kc * 4;                 // gathered channel (dgrad: == forward output channel)
-      t_kv = live & ((pos * g.C + t_ci) < g.K);
-      t_kh = kh_run;
-      t_kw = kw_run;
+      // K = npos * C and C is a multiple of BK (launcher): a live tile lies inside one tap, all of its k are valid
       t_fpos = g.flip ? (g.npos - 1 - pos) : pos;
-      t_aoff = ((kh_run * g.W + kw_run) * g.C + t_ci) * 4;   // scalar multiplies + one vector add
+      s_a = live ? (unsigned)(((kh_run * g.W + kw_run) * g.C + ci0) * 4) : kOOB;
+      s_sh = (unsigned)(31 - pos);
+      s_b = !live ? kOOB : BMODE == 0 ? (unsigned)kt * (unsigned)b_tile_bytes
+                                      : ((unsigned)t_fpos * (unsigned)g.cin_fwd * (unsigned)g.ldw + (unsigned)ci0) * 4u;
       // raw value; consumed (and replaced by 1 when there is no in_scale: empty descriptor, reads 0) only at the LDS
       // store one tile later -- touching it here would make the wave wait for the load it has just issued
-      if (BMODE == 1) st.s = buf_load4(rscale, t_kv ? (unsigned)t_ci * 4u : kOOB);   // forward never scales its input
+      if (BMODE == 1) st.s = buf_load4s(rscale, (unsigned)a_kc * 16u, live ? (unsigned)ci0 * 4u : kOOB);   // forward never scales its input
       // advance the running position to the following tile
       ci0 += BK;
       const bool wrap = ci0 >= g.C;
@@ -391,10 +427,14 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     if (idx < A_ITERS) {
       // ---------------- A: implicit im2col gather (invalid taps load from kOOB -> 0)
       const int i = idx;
-      const int ih = a_ih0[i] + t_kh, iw = a_iw0[i] + t_kw;
-      const bool ok = t_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-      st.a[i] = buf_load4(rx, ok ? (unsigned)(a_base[i] + t_aoff) : kOOB);
-    } else if (BMODE == 0) {
+      if (SMALLC) {
+        const int ih = a_ih0[i] + t_kh, iw = a_iw0[i] + t_kw;
+        const bool ok = t_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+        st.a[i] = buf_load4(rx, ok ? (unsigned)(a_base[i] + t_aoff) : kOOB);
+      } else {
+        st.a[i] = buf_load4s(rx, a_voff[i] | ((a_inv[i] << s_sh) & kOOB), s_a);       // two VALU: padding bit of this tap -> bit 31
+      }
+    } else if (SMALLC) {
       constexpr int CPR = BN / 4;            // float4 chunks per k row
       const int i = idx - A_ITERS;
       const int c = tid + NT * i;
@@ -402,10 +442,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
       const bool ok = t_live & (t_kt * BK + kr < g.K) & b_nvalid[i];   // N is a multiple of 4 (launcher checks)
       st.b[i] = buf_load4(rw, ok ? (unsigned)(b_base[i] + t_kt * b_tile_bytes) : kOOB);
     } else {
-      const int i = idx - A_ITERS;
-      const int n = n0 + (tid >> 3) + kRowStep * i;   // forward input channel
-      const bool ok = t_kv & (n < g.N);
-      st.b[i] = buf_load4(rw, ok ? (((unsigned)t_fpos * (unsigned)g.cin_fwd + (unsigned)n) * (unsigned)g.ldw + (unsigned)t_ci) * 4u : kOOB);
+      st.b[idx - A_ITERS] = buf_load4s(rw, b_voff[idx - A_ITERS], s_b);            // no VALU at all
     }
   };
 
@@ -480,7 +517,16 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
           load_op(s, cur);
 #endif
         } else if (s < kSteps - 1) {
-#ifndef RADNET_DIAG_SKIP_STORES
+#if defined(RADNET_DIAG_SINK_STORES)         // loads stay (consumed by an empty asm after their wait), the LDS stores go
+#pragma unroll
+          for (int q = 0; q < kStoresPerStep; ++q) {
+            const int op = (s - kLoadOps) * kStoresPerStep + q;
+            if (op < kStoreOps) {
+              const float4 v = op < A_ITERS ? nxt.a[op < A_ITERS ? op : 0] : nxt.b[op < A_ITERS ? 0 : op - A_ITERS];
+              asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            }
+          }
+#elif !defined(RADNET_DIAG_SKIP_STORES)
 #pragma unroll
           for (int q = 0; q < kStoresPerStep; ++q) {
             const int op = (s - kLoadOps) * kStoresPerStep + q;
@@ -1023,6 +1069,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   if ((g.ldw & 3) || (g.N & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: N=%d and ldw=%d must be multiples of 4", g.N, g.ldw);
   if (((uintptr_t)g.x & 15) || ((uintptr_t)g.w & 15)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: x / w must be 16-byte aligned");
   if (!smallc && (g.C % BK) != 0) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: channels %d not a multiple of %d (pad, or use c=4)", g.C, BK);
+  if (!smallc && g.npos > 32) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: %d kernel taps (the padding mask of a row holds 32)", g.npos);
   g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
   g.magic_ow = radnet_div_magic((uint32_t)g.OW);
   {
