@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   constexpr int kLoadOps = A_ITERS + B_ITERS;                                   // one 16-byte buffer load each
   constexpr int kStoreOps = A_ITERS + B_ITERS;                                  // one ds_write_b128 each
   // state of the tile being loaded (tile_begin -> load_op)
-  int t_kt = 0, t_ci = 0, t_kh = 0, t_kw = 0, t_fpos = 0, t_aoff = 0;
+  int t_kt = 0, t_kh = 0, t_kw = 0, t_fpos = 0, t_aoff = 0;
   bool t_live = false, t_kv = false;
   unsigned s_a = kOOB, s_b = kOOB, s_sh = 0;       // wave-uniform: SGPR offsets of the tile's A / B loads, tap -> bit-31 shift
 
@@ -725,7 +725,9 @@ struct WgradArgs {
   int ld_dy, ldw;
   int mt_per_split;
   int atomic;
-  const int2* rowtab;    // [M] {byte offset of the row's window origin, ih0 | iw0 << 16}, see get_row_table
+  const int* rowtab;     // [taps][mpad] byte offset of the row's tap in the biased x descriptor, or kOOB; see get_row_table
+  int mpad;              // M rounded up to whole 32-row tiles
+  unsigned x_bias;       // bytes the x descriptor starts ahead of x (halo rows keep non-negative offsets)
   unsigned x_bytes, dy_bytes;
   int batch, splits;     // batch > 1: blockIdx.z = problem * splits + split (radnet_wgrad_batched)
   long long x_bstride, dy_bstride, dw_bstride;   // floats between consecutive problems
@@ -750,7 +752,6 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   // this block's k range lies inside one kernel position when C % BMK == 0 (launcher guarantees)
   const int pos = k0 / g.C;
   const int cbase = k0 - pos * g.C;
-  const int kh = pos / g.KW, kw = pos - kh * g.KW;
 
   const int a_k4 = tid % CPRA, a_mr = tid / CPRA;      // A_ITERS rows: a_mr + (NTHREADS/CPRA)*i
   const int b_n4 = tid % CPRB, b_mr = tid / CPRB;
@@ -766,7 +767,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   int mt_end = mt_begin + g.mt_per_split;
   if (mt_end > nmt) mt_end = nmt;
 
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x + bp * g.x_bstride, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(g.x + bp * g.x_bstride) - g.x_bias, g.x_bytes + g.x_bias);
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(g.dy + bp * g.dy_bstride, g.dy_bytes);
   float4 ra[A_ITERS], rb[B_ITERS];
   // bias gradient: the workgroups of the first k tile see every (dy * gscale) row of their m range exactly once on
@@ -775,40 +776,38 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   const bool do_bias = g.db != nullptr && blockIdx.x == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // Row table (host-built once per conv geometry, get_row_table): rowtab[m] = {byte offset of (image, ih0, iw0,
-  // channel 0) -- possibly negative in the halo --, ih0 & 0xFFFF | iw0 << 16}.  The reduction index m advances by 32
-  // per tile, so decoding m -> (image, oh, ow) inside the loop cost two multiply-high divisions and three 16-cycle
-  // multiplies per load; with the table a load is two adds and two range compares.  The entries of tile t+2 are
-  // fetched while tile t is multiplied, one tile ahead of the loads that use them.
-  const __amdgpu_buffer_rsrc_t rtab = make_rsrc(g.rowtab, (unsigned)g.M * 8u);
-  const int tap_off = ((kh * g.W + kw) * g.C + cbase + a_k4 * 4) * 4;
-  int b_off0[B_ITERS];
+  // Row table (host-built once per conv geometry, get_row_table): rowtab[tap][m] = byte offset of input pixel
+  // (image, ih0 + kh, iw0 + kw, channel 0) of output row m -- kOOB where the tap falls into the padding or m >= M.  The
+  // reduction index m advances by 32 per tile, so decoding m -> (image, oh, ow) inside the loop cost two multiply-high
+  // divisions and three 16-cycle multiplies per load; with the table the gather is ONE vector add per load, everything
+  // tile-dependent (table row, channel base, dy row, "tile past the end") is wave-uniform and sits in the loads' SGPR
+  // offset (see conv_igemm_kernel).  The entries of tile t+2 are fetched while tile t is multiplied, one tile ahead of
+  // the loads that use them.
+  const __amdgpu_buffer_rsrc_t rtab = make_rsrc(g.rowtab + (size_t)pos * g.mpad, (unsigned)g.mpad * 4u);
+  const unsigned s_tap = (unsigned)(cbase * 4);            // the tap is in the table; the k tile adds its first channel
+  unsigned b_voff[B_ITERS], e_voff[A_ITERS];
 #pragma unroll
-  for (int i = 0; i < B_ITERS; ++i) b_off0[i] = ((b_mr + (NTHREADS / CPRB) * i) * g.ld_dy + n0 + b_n4 * 4) * 4;
-  const int dy_tile_bytes = BK * g.ld_dy * 4;
+  for (int i = 0; i < B_ITERS; ++i) b_voff[i] = b_nv ? (unsigned)(((b_mr + (NTHREADS / CPRB) * i) * g.ld_dy + n0 + b_n4 * 4) * 4) : kOOB;
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) e_voff[i] = (unsigned)((a_mr + (NTHREADS / CPRA) * i) * 4);
+  const unsigned a_lane = a_kv ? (unsigned)a_k4 * 16u : kOOB;
+  const unsigned dy_tile_bytes = (unsigned)(BK * g.ld_dy * 4);
   struct Entries {
-    int2 e[A_ITERS];
+    unsigned e[A_ITERS];
   };
   Entries ent0, ent1;
 
   constexpr int kLoadOps = A_ITERS + B_ITERS, kStoreOps = A_ITERS + B_ITERS;
   auto entry_op = [&](int i, int mt, Entries& en) {
-    const int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
-    en.e[i] = buf_load2i(rtab, ((mt < mt_end) & (m < g.M)) ? (unsigned)m * 8u : kOOB);
+    en.e[i] = __builtin_amdgcn_raw_buffer_load_b32(rtab, (int)e_voff[i], (int)__builtin_amdgcn_readfirstlane(mt < mt_end ? (unsigned)mt * (BK * 4u) : kOOB), 0);
   };
   auto load_op = [&](int idx, int mt, const Entries& en) {
+    const bool live = mt < mt_end;         // a dead tile's table entries read 0: its loads go out of range through the SGPR offset
     if (idx < A_ITERS) {
-      const int i = idx;
-      const int m = mt * BK + a_mr + (NTHREADS / CPRA) * i;
-      const int2 e = en.e[i];
-      const int ih = ((e.y << 16) >> 16) + kh, iw = (e.y >> 16) + kw;
-      const bool ok = (mt < mt_end) & (m < g.M) & a_kv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-      ra[i] = buf_load4(rx, ok ? (unsigned)(e.x + tap_off) : kOOB);
+      ra[idx] = buf_load4s(rx, en.e[idx] + a_lane, live ? s_tap : kOOB);
     } else {
-      const int i = idx - A_ITERS;
-      const int m = mt * BK + b_mr + (NTHREADS / CPRB) * i;
-      const bool ok = (mt < mt_end) & (m < g.M) & b_nv;
-      rb[i] = buf_load4(rdy, ok ? (unsigned)(b_off0[i] + mt * dy_tile_bytes) : kOOB);
+      // rows past M lie past the end of the dy descriptor
+      rb[idx - A_ITERS] = buf_load4s(rdy, b_voff[idx - A_ITERS], live ? (unsigned)mt * dy_tile_bytes : kOOB);
     }
   };
   auto store_op = [&](int idx, int buf) {
@@ -1024,25 +1023,30 @@ radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, 
 // of its window origin (image, oh*stride - pad_t, ow*stride - pad_l, channel 0) in x -- negative inside the halo -- and
 // the origin's (ih0, iw0) packed into 16 + 16 bits.  Built on the host at the first use of a geometry, cached on the
 // context (device memory, freed with it).
-const int2* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
-  const std::array<int, 9> key{d->nb, d->h, d->w_, d->c, d->oh, d->ow, d->stride, d->pad_t, d->pad_l};
+const int* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  const std::array<int, 11> key{d->nb, d->h, d->w_, d->c, d->oh, d->ow, d->stride, d->pad_t, d->pad_l, d->kh, d->kw};
   auto it = ctx->row_tables.find(key);
-  if (it != ctx->row_tables.end()) return (const int2*)it->second;
-  const int M = d->nb * d->oh * d->ow;
-  std::vector<int> host((size_t)M * 2);
-  size_t m = 0;
-  for (int img = 0; img < d->nb; ++img)
-    for (int oh = 0; oh < d->oh; ++oh)
-      for (int ow = 0; ow < d->ow; ++ow, ++m) {
-        const int ih0 = oh * d->stride - d->pad_t, iw0 = ow * d->stride - d->pad_l;
-        host[2 * m] = (int)((((int64_t)img * d->h + ih0) * d->w_ + iw0) * d->c * 4);
-        host[2 * m + 1] = (int)(((unsigned)ih0 & 0xFFFFu) | ((unsigned)iw0 << 16));
-      }
+  if (it != ctx->row_tables.end()) return (const int*)it->second;
+  const int M = d->nb * d->oh * d->ow, mpad = radnet_cdiv(M, BK) * BK, taps = d->kh * d->kw;
+  const int64_t bias = ((int64_t)d->pad_t * d->w_ + d->pad_l) * d->c * 4;
+  std::vector<uint32_t> host((size_t)taps * mpad, 0x80000000u);
+  for (int kh = 0; kh < d->kh; ++kh)
+    for (int kw = 0; kw < d->kw; ++kw) {
+      uint32_t* row = host.data() + (size_t)(kh * d->kw + kw) * mpad;
+      size_t m = 0;
+      for (int img = 0; img < d->nb; ++img)
+        for (int oh = 0; oh < d->oh; ++oh)
+          for (int ow = 0; ow < d->ow; ++ow, ++m) {
+            const int ih = oh * d->stride - d->pad_t + kh, iw = ow * d->stride - d->pad_l + kw;
+            if ((unsigned)ih < (unsigned)d->h && (unsigned)iw < (unsigned)d->w_)
+              row[m] = (uint32_t)((((int64_t)img * d->h + ih) * d->w_ + iw) * d->c * 4 + bias);
+          }
+    }
   void* dev = nullptr;
-  if (hipMalloc(&dev, host.size() * sizeof(int)) != hipSuccess) return nullptr;
-  if (hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (hipMalloc(&dev, host.size() * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   ctx->row_tables.emplace(key, dev);
-  return (const int2*)dev;
+  return (const int*)dev;
 }
 
 template <int BMODE, bool SMALLC, int WAVES>
@@ -1261,6 +1265,8 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   if (d->h >= 32768 || d->w_ >= 32768) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: input %dx%d exceeds the 16-bit row table", d->h, d->w_);
   g.rowtab = get_row_table(ctx, d);
   if (!g.rowtab) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv_wgrad: cannot build the row table");
+  g.mpad = radnet_cdiv(g.M, BK) * BK;
+  g.x_bias = (unsigned)(((int64_t)d->pad_t * d->w_ + d->pad_l) * d->c * 4);
   {
     const uint64_t xb = (uint64_t)d->nb * d->h * d->w_ * d->c * 4ull, db = (uint64_t)g.M * g.ld_dy * 4ull;
     if (xb >= (1ull << 31) || db >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: tensor larger than 2 GiB");

@@ -48,7 +48,7 @@ struct radnet_ctx {
   // measured launch choices; contexts of one engine share ONE table (radnet_share_tuning), calls come from one host thread
   std::shared_ptr<std::map<radnet_shape_key, radnet_tuned>> tuned = std::make_shared<std::map<radnet_shape_key, radnet_tuned>>();
   std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
-  std::map<std::array<int, 9>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)
+  std::map<std::array<int, 11>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)
   hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
