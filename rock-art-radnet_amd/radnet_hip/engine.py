@@ -510,14 +510,15 @@ class FasterRCNNEngine:
             elif kind == "colsum":
                 g, m, n, ld, gs, out, acc = p
                 rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, acc)
-            elif kind == "wino":           # stride-1 'same' 3x3 conv as Winograd F(2x2,3x3): transform, 16 GEMMs, transform
+            elif kind in ("wino", "wino_reuse"):   # ("wino_reuse": V already holds this input's transform)
+                # stride-1 'same' 3x3 conv as Winograd F(2x2,3x3): transform, 16 GEMMs, transform
                 x, nb, hh, ww, c, n, V, U, M, T, scale, shift, act, y, ldy = p
                 timed = self.ctx.timing_on
                 if timed:                  # roofline leg: the LAYER is timed (three kernels) and credited its algorithmic flops
                     self.ctx.timing(False)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                rc = lib.radnet_winograd_input(h, x, nb, hh, ww, c, V)
+                rc = lib.radnet_winograd_input(h, x, nb, hh, ww, c, V) if kind == "wino" else 0
                 if rc == 0:
                     rc = lib.radnet_gemm_batched(h, V, U, M, 16, T, n, c)
                 if rc == 0:
@@ -681,7 +682,9 @@ class FasterRCNNEngine:
                ("dgrad", b2), wg1, ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
         bwd = self._fuse_bias_grads(bwd)
         ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
-        plan = dict(fwd=[op1, ("conv", d2)], bwd=bwd, b1=b1, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
+        # the re-prediction after Adam #1 (train.py:291) sees the same feature map: its input transform is already in V
+        refwd = [("wino_reuse", op1[1]) if op1[0] == "wino" else op1, ("conv", d2)]
+        plan = dict(fwd=[op1, ("conv", d2)], refwd=refwd, bwd=bwd, b1=b1, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
                     R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
                     Rn=torch.zeros(1, dtype=torch.int32, device=dev))

@@ -159,7 +159,7 @@ class TrainStep:
         st["roi"] = []
         for i, bp in enumerate(plans):
             s = batch[i]
-            eng._run(rps[i]["fwd"])
+            eng._run(rps[i].get("refwd", rps[i]["fwd"]))      # same feature map as the first pass: no second input transform
             R, Rn = eng.proposals(rps[i], overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
             st["roi"].append((R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i)))
