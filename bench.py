@@ -95,7 +95,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     dist = None
-    if world > 1:
+    nccl1 = os.environ.get("RADNET_BENCH_REHEARSAL") == "nccl1" and world == 1
+    if nccl1:
+        # rehearsal of the RCCL code path on ONE GPU: a 1-rank process group, both gradient exchanges issued (identity
+        # reductions) from the lanes they are issued from on N GPUs, head update deferred as on N GPUs
+        import torch.distributed as dist
+        from radnet_hip import trainer as _tr
+        _tr.FORCE_COLLECTIVES = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("RADNET_BENCH_REHEARSAL") == "1":
@@ -142,7 +154,7 @@ def main():
     else:
         eng = FasterRCNNEngine(C, device_index=local_rank)
         eng.set_weights(synth.synthetic_weights(seed=3))
-        ts = TrainStep(eng, world_size=world)
+        ts = TrainStep(eng, world_size=world, defer_head_update=True if nccl1 else None)
     have_cache = args.tune_cache is not None and os.path.exists(args.tune_cache)
     if have_cache:
         eng.load_tuning(args.tune_cache)

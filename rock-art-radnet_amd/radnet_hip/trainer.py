@@ -32,11 +32,14 @@ def new_img_size(width, height, min_side):
     return int(f * width), min_side
 
 
+FORCE_COLLECTIVES = False      # rehearsal hook (bench.py RADNET_BENCH_REHEARSAL=nccl1): issue the exchanges on a 1-rank group too
+
+
 def allreduce_grad_arena(flat, world, group=None):
     """Data-parallel exchange of one optimizer's flat gradient arena: SUM over ranks (RCCL over xGMI on the GPUs,
     gloo in the CPU tests).  Returns the factor Adam applies to the summed gradient so that the update uses the MEAN
     over all `world * images_per_rank` images (the caller divides by images_per_rank as well)."""
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVES:
         import torch.distributed as dist
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
@@ -45,7 +48,7 @@ def allreduce_grad_arena(flat, world, group=None):
 def allreduce_grad_arena_start(flat, world, group=None):
     """The same exchange, asynchronous: returns a handle whose wait() orders the CURRENT stream after the reduction
     (None on a single rank).  The collective runs on the backend's own stream, beside whatever is enqueued next."""
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVES:
         import torch.distributed as dist
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
