@@ -21,6 +21,11 @@ for _p in (ROOT, os.path.join(ROOT, "rock-art-radnet_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# The step keeps 4 HIP streams busy (three lanes + the upload stream) and RCCL adds one per communicator; HIP multiplexes
+# streams over 4 hardware queues by default, and two busy streams that land on one queue serialise (measured: the
+# pipelined step 385 instead of 441 images/s once RCCL's streams exist).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -154,7 +159,8 @@ def main():
     else:
         eng = FasterRCNNEngine(C, device_index=local_rank)
         eng.set_weights(synth.synthetic_weights(seed=3))
-        ts = TrainStep(eng, world_size=world, defer_head_update=True if nccl1 else None)
+        _defer = os.environ.get("RADNET_BENCH_DEFER")          # experiment knob: force the deferred / immediate head update
+        ts = TrainStep(eng, world_size=world, defer_head_update=(_defer == "1") if _defer is not None else (True if nccl1 else None))
     have_cache = args.tune_cache is not None and os.path.exists(args.tune_cache)
     if have_cache:
         eng.load_tuning(args.tune_cache)

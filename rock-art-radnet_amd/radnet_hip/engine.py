@@ -764,10 +764,12 @@ class FasterRCNNEngine:
         dfeat = buf(R, 2048)
         # backward program (train.py mode: nothing flows below the RoI crop, the base is frozen)
         bwd = []
+        bwd_parts = []                         # the same program cut per block, last block first (bucketed gradient exchange)
         g_out = buf(M, f3)                     # gradient w.r.t. the last block's output, ReLU mask applied
         g_first = g_out
         for bi in range(len(blocks) - 1, -1, -1):
             B = blocks[bi]
+            part_from = len(bwd)
             ca, cb, cc = (self.convs[n] for n in B["names"][:3])
             g_b, g_a = buf(M, f2), buf(M, f1)
 
@@ -799,8 +801,15 @@ class FasterRCNNEngine:
                 dA = bdesc(B["da"], ca, g_a, f1, g_prev, f3, g_out, B["x"])
                 bwd += [("wgrad", dA), ("colsum", [g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr(), 1]), ("dgrad", dA)]
                 g_out = g_prev
-        bwd = self._fuse_bias_grads(bwd)
-        plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
+            # gradient slice of this block's kernels: contiguous in the arena (kernels are laid out in forward order)
+            k0 = self.head_arena.offsets[B["names"][0] + "/kernel"][0]
+            kl, sl = self.head_arena.offsets[B["names"][3 if B["first"] else 2] + "/kernel"]
+            bwd_parts.append((self._fuse_bias_grads(bwd[part_from:]), (k0, kl + _pad4(sl))))
+        bwd = [op for part, _ in bwd_parts for op in part]
+        cover = sorted(sl for _, sl in bwd_parts)
+        if cover[0][0] != 0 or cover[-1][1] != self.head_bias_off or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
+            raise RuntimeError("head gradient buckets do not tile the kernel part of the arena: %r" % (cover,))
+        plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
         self._plans[key] = plan
         return plan
@@ -813,14 +822,23 @@ class FasterRCNNEngine:
         self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                       hp["pcls"], hp["pregr"])
 
-    def head_backward(self, hp, accumulate=False, loss_out=None):
-        """losses (losses.py:69-95) + gradients of every stage-5 conv and both dense heads into the head grad arena."""
+    def head_backward(self, hp, accumulate=False, loss_out=None, on_part=None):
+        """losses (losses.py:69-95) + gradients of every stage-5 conv and both dense heads into the head grad arena.
+        on_part(lo, hi): called after each block of the backward program (last block first) with the slice [lo, hi) of
+        the flat gradient arena that block has just completed -- the data-parallel trainer starts that slice's all-reduce
+        while the earlier blocks are still being differentiated; the biases and the dense heads (the arena's tail from
+        head_bias_off) are complete when the call returns."""
         self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
                       self.det_losses if loss_out is None else loss_out)
         self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
                       self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
-        self._run(hp["bwd"], overlap=True)
+        if on_part is None or "bwd_parts" not in hp:
+            self._run(hp["bwd"], overlap=True)
+            return
+        for part, (lo, hi) in hp["bwd_parts"]:
+            self._run(part, overlap=True)
+            on_part(lo, hi)
 
     # ------------------------------------------------------------------------------------------ targets
     def upload_gt(self, gt_boxes, gt_is_bg, gt_cls):

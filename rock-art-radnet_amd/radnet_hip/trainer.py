@@ -67,6 +67,15 @@ class TrainStep:
         self.eng = eng
         self.world = world_size
         self.group = dist_group
+        # The two exchanges run on different lanes and belong to different batches (AR#1 of batch i+1 is issued before
+        # AR#2 of batch i): on ONE communicator they would queue on its single internal stream, AR#1 of the next batch
+        # behind an AR#2 that waits for a head backward -- the RPN chain would inherit the head lane's latency.  The head
+        # exchange therefore gets its own communicator (created by all ranks here, in the same order).
+        self.group_head = dist_group
+        if world_size > 1 or FORCE_COLLECTIVES:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.group_head = dist.new_group(ranks=None if dist_group is None else dist.get_process_group_ranks(dist_group))
         self.defer_head_update = (world_size > 1) if defer_head_update is None else bool(defer_head_update)
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self._head_done = {}             # buffer set -> event: end of the head phase that last read its feature map
@@ -84,15 +93,16 @@ class TrainStep:
         self._det_l = torch.zeros(self.NBUF, 64, 3, dtype=torch.float32, device=dev)
 
     def _allreduce(self, arena):
-        allreduce_grad_arena(arena.g, self.world, self.group)
+        allreduce_grad_arena(arena.g, self.world, self.group_head if arena is self.eng.head_arena else self.group)
 
     def _finish_head_update(self):
         if self._head_pending is None:
             return
-        work, ntot = self._head_pending
+        works, ntot = self._head_pending
         self._head_pending = None
-        if work is not None:
-            work.wait()
+        for work in works if isinstance(works, (list, tuple)) else [works]:
+            if work is not None:
+                work.wait()
         self.eng.adam(self.eng.head_arena, grad_scale=1.0 / ntot)
         self.eng.refresh_head_shift()
 
@@ -267,6 +277,16 @@ class TrainStep:
         head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
         slot = st["slot"]
         n_head = 0
+        live = [i for i in range(nloc) if picks[i] is not None]
+        # Bucketed exchange (deferred mode): during the LAST local image's backward each block's kernel gradients are
+        # final as soon as that block is differentiated -- their all-reduce starts then, beside the blocks still to come
+        # (res5c 18 MB, res5b 18 MB, res5a 24 MB); only the last slice and the small tail are left at the end.
+        bucketed = self.defer_head_update and (self.world > 1 or FORCE_COLLECTIVES) and bool(live) and hasattr(eng, "head_bias_off")
+        works = []
+
+        def exchange(lo, hi):
+            works.append(allreduce_grad_arena_start(eng.head_arena.g[lo:hi], self.world, self.group_head))
+
         with head_lane():      # what it reads from the other lanes (feature map, RoI labels) is complete: the host waited
             for i, bp in enumerate(st["plans"]):
                 if picks[i] is None:
@@ -276,12 +296,18 @@ class TrainStep:
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
                 eng.head_forward(hp, training=True)
                 eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
-                eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head])
+                if bucketed and i == live[-1] and "bwd_parts" in hp:
+                    eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head], on_part=exchange)
+                else:
+                    eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head])
                 n_head += 1
             if n_head > 0 or self.world > 1:
                 self._finish_head_update()               # only still pending when every local image skipped its head phase
-                if self.defer_head_update:
-                    self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group), ntot)
+                if self.defer_head_update and works:     # kernels are on their way: biases + dense heads follow
+                    exchange(eng.head_bias_off, eng.head_arena.n)
+                    self._head_pending = (works, ntot)
+                elif self.defer_head_update:
+                    self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group_head), ntot)
                 else:
                     self._allreduce(eng.head_arena)
                     eng.adam(eng.head_arena, grad_scale=1.0 / ntot)

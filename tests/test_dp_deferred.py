@@ -35,8 +35,10 @@ class FakeEngine:
     """Implements exactly what TrainStep.step touches; gradients are rank- and step-dependent constants and 'Adam' is
     p -= grad_scale * g followed by clearing g (the zero_grad contract of the real engine)."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, bucketed=False):
         self.rank = rank
+        if bucketed:
+            self.head_bias_off = 6     # arena of 8: three "blocks" of 2 + a tail of 2 (biases, dense heads)
         self.dev = "cpu"
         self.bg = 1
         self.C = types.SimpleNamespace(class_mapping={"fg": 0, "bg": 1}, img_size=600, n_rois=4)
@@ -93,7 +95,7 @@ class FakeEngine:
         return P, np.array([0, 1, 0, 1, 1], dtype=np.int32), 5
 
     def _plan_head(self, R, fh, fw, F):
-        return dict(bwd=[])
+        return dict(bwd=[], bwd_parts=[([], (4, 6)), ([], (2, 4)), ([], (0, 2))])
 
     def pack_roi_batch(self, P, sel, hp):
         pass
@@ -101,11 +103,15 @@ class FakeEngine:
     def head_forward(self, hp, training=False):
         self.log.append(("head_fwd", self.k, float(self.head_arena.p[0])))
 
-    def head_backward(self, hp, accumulate=True, loss_out=None):
+    def head_backward(self, hp, accumulate=True, loss_out=None, on_part=None):
         self.head_arena.g += float((self.rank + 1) * (self.k + 1))
+        if on_part is not None:            # the real engine reports each block's finished kernel-gradient slice
+            self.log.append(("bucketed", self.k))
+            for _, (lo, hi) in hp["bwd_parts"]:
+                on_part(lo, hi)
 
 
-def _worker(rank, world, port, out, defer):
+def _worker(rank, world, port, out, defer, bucketed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -118,7 +124,7 @@ def _worker(rank, world, port, out, defer):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     np.random.seed(64 + rank)
-    eng = FakeEngine(rank)
+    eng = FakeEngine(rank, bucketed)
     ts = TrainStep(eng, world_size=world, defer_head_update=defer)
     batch = [dict(img=np.zeros((4, 4, 3), np.uint8), bboxes=[dict({"class": "fg"}, x1=0, x2=2, y1=0, y2=2)], width=8, height=8)]
     for _ in range(3):
@@ -130,13 +136,16 @@ def _worker(rank, world, port, out, defer):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("defer", [True, False])
-def test_deferred_head_update_order_and_value(defer):
+@pytest.mark.parametrize("defer,bucketed", [(True, False), (True, True), (False, False)])
+def test_deferred_head_update_order_and_value(defer, bucketed):
+    """bucketed: the engine reports each block's finished gradient slice during the backward and the trainer exchanges the
+    slices one by one (+ the arena's tail at the end): every element must still be reduced exactly once."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out, defer), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, defer, bucketed), nprocs=world, join=True)
     (log0, hp0, rp0), (log1, hp1, rp1) = out[0], out[1]
+    assert any(e[0] == "bucketed" for e in log0) == bucketed
     assert np.array_equal(hp0, hp1) and np.array_equal(rp0, rp1)          # replicas stay identical
     # head update of step k: sum over ranks of (rank+1)(k+1) = 3(k+1), scaled by 1/global batch (2 images)
     upd = [1.5 * (k + 1) for k in range(3)]
