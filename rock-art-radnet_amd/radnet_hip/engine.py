@@ -809,10 +809,34 @@ class FasterRCNNEngine:
         cover = sorted(sl for _, sl in bwd_parts)
         if cover[0][0] != 0 or cover[-1][1] != self.head_bias_off or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
             raise RuntimeError("head gradient buckets do not tile the kernel part of the arena: %r" % (cover,))
+        if [sl for _, sl in bwd_parts] != self.head_exchange_slices():
+            raise RuntimeError("head backward parts and head_exchange_slices() disagree")
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
         self._plans[key] = plan
         return plan
+
+    def head_exchange_slices(self):
+        """Slices [lo, hi) of the flat head gradient arena in the order head_backward(on_part=...) completes them (last
+        block first), or None when this engine's head backward is not cut per block.  Every rank of a data-parallel job
+        must issue the same sequence of collectives, also a rank whose images all skipped their classifier step."""
+        if not hasattr(self, "_head_slices"):
+            self._head_slices = None
+            names = getattr(self, "head_conv_names", [])
+            blocks = []
+            for n in names:                     # res5a_branch2a ... -> block prefix 'res5a'
+                b = n.split("_")[0]
+                if not blocks or blocks[-1][0] != b:
+                    blocks.append([b, n, n])
+                blocks[-1][2] = n
+            if blocks and all(n.startswith("res5") for n in names):
+                sl = []
+                for _, first, last in blocks:
+                    o0 = self.head_arena.offsets[first + "/kernel"][0]
+                    ol, szl = self.head_arena.offsets[last + "/kernel"]
+                    sl.append((o0, ol + _pad4(szl)))
+                self._head_slices = sl[::-1]
+        return self._head_slices
 
     def head_forward(self, hp, training=False):
         """classifier_layer forward (`training` only matters for the VGG16 head's Dropout)."""

@@ -281,7 +281,8 @@ class TrainStep:
         # Bucketed exchange (deferred mode): during the LAST local image's backward each block's kernel gradients are
         # final as soon as that block is differentiated -- their all-reduce starts then, beside the blocks still to come
         # (res5c 18 MB, res5b 18 MB, res5a 24 MB); only the last slice and the small tail are left at the end.
-        bucketed = self.defer_head_update and (self.world > 1 or FORCE_COLLECTIVES) and bool(live) and hasattr(eng, "head_bias_off")
+        slices = eng.head_exchange_slices() if hasattr(eng, "head_exchange_slices") else None
+        bucketed = self.defer_head_update and (self.world > 1 or FORCE_COLLECTIVES) and slices is not None
         works = []
 
         def exchange(lo, hi):
@@ -296,15 +297,18 @@ class TrainStep:
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
                 eng.head_forward(hp, training=True)
                 eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
-                if bucketed and i == live[-1] and "bwd_parts" in hp:
+                if bucketed and i == live[-1]:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head], on_part=exchange)
                 else:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head])
                 n_head += 1
             if n_head > 0 or self.world > 1:
                 self._finish_head_update()               # only still pending when every local image skipped its head phase
-                if self.defer_head_update and works:     # kernels are on their way: biases + dense heads follow
-                    exchange(eng.head_bias_off, eng.head_arena.n)
+                if bucketed:
+                    if not works:                        # every local image skipped its classifier step: the other ranks
+                        for lo, hi in slices:            # still exchange slice by slice -- same collectives, zeros from here
+                            exchange(lo, hi)
+                    exchange(eng.head_bias_off, eng.head_arena.n)      # biases + dense heads
                     self._head_pending = (works, ntot)
                 elif self.defer_head_update:
                     self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group_head), ntot)

@@ -35,16 +35,20 @@ class FakeEngine:
     """Implements exactly what TrainStep.step touches; gradients are rank- and step-dependent constants and 'Adam' is
     p -= grad_scale * g followed by clearing g (the zero_grad contract of the real engine)."""
 
-    def __init__(self, rank, bucketed=False):
+    def __init__(self, rank, bucketed=False, skip_step=None):
         self.rank = rank
-        if bucketed:
-            self.head_bias_off = 6     # arena of 8: three "blocks" of 2 + a tail of 2 (biases, dense heads)
+        self.skip_step = skip_step     # this rank finds no RoI to train on in that step (calc_iou -> None in the reference)
+        self.bucketed = bucketed
+        self.head_bias_off = 6         # arena of 8: three "blocks" of 2 + a tail of 2 (biases, dense heads)
         self.dev = "cpu"
         self.bg = 1
         self.C = types.SimpleNamespace(class_mapping={"fg": 0, "bg": 1}, img_size=600, n_rois=4)
         self.rpn_arena, self.head_arena = _Arena(8), _Arena(8)
         self.log = []
         self.k = -1            # step index, advanced by the first call of a step
+
+    def head_exchange_slices(self):
+        return [(4, 6), (2, 4), (0, 2)] if self.bucketed else None
 
     def upload_gt(self, boxes, isbg, cls):
         return dict(g=len(boxes))
@@ -90,8 +94,9 @@ class FakeEngine:
     def roi_targets_launch(self, R, Rn, gt, width, height, rw, rh, slot=0):
         return dict()
 
-    @staticmethod
-    def roi_targets_finish(P):
+    def roi_targets_finish(self, P):
+        if self.skip_step is not None and self.k == self.skip_step:
+            return P, np.zeros(0, dtype=np.int32), 0
         return P, np.array([0, 1, 0, 1, 1], dtype=np.int32), 5
 
     def _plan_head(self, R, fh, fw, F):
@@ -166,6 +171,44 @@ def test_deferred_head_update_order_and_value(defer, bucketed):
             # immediate: before step k even starts
             assert (i_upd > i_rpn) == defer
         assert any(e[0] == "refresh" for e in log)
+
+
+def _worker_skip(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "rock-art-radnet_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from radnet_hip.trainer import TrainStep
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    np.random.seed(64 + rank)
+    eng = FakeEngine(rank, bucketed=True, skip_step=1 if rank == 1 else None)
+    ts = TrainStep(eng, world_size=world, defer_head_update=True)
+    batch = [dict(img=np.zeros((4, 4, 3), np.uint8), bboxes=[dict({"class": "fg"}, x1=0, x2=2, y1=0, y2=2)], width=8, height=8)]
+    for _ in range(3):
+        ts.step(batch)
+    ts.flush()
+    out[rank] = (eng.head_arena.p.numpy().copy(), ts.skipped_head_steps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_exchange_when_one_rank_skips_its_head_step():
+    """Rank 1 has nothing to train the classifier on in step 1: it must still issue the SAME sequence of slice exchanges
+    (zeros from its side) or the job hangs; the update of that step is then rank 0's gradient alone over the global batch."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_skip, args=(world, _free_port(), out), nprocs=world, join=True)
+    (hp0, sk0), (hp1, sk1) = out[0], out[1]
+    assert (sk0, sk1) == (0, 1) and np.array_equal(hp0, hp1)
+    # steps 0 and 2: (1 + 2) * (k + 1) / 2 images; step 1: rank 0 only -> 1 * 2 / 2
+    assert np.allclose(hp0, -(1.5 * 1 + 1.0 + 1.5 * 3))
 
 
 class FakeContEngine(FakeEngine):

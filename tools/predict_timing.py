@@ -1,51 +1,39 @@
-"""Wall time of the predict.py path (RADNet.predict on one 2048x2048 synthetic tile, BASELINE cfg 3) and where the host
-spends it.  usage: python tools/predict_timing.py [img_size]"""
-import cProfile
-import os
-import pstats
-import sys
-import time
-
+"""Time the predict path (RADNet._detect: resize -> RPN -> proposals -> classifier on all RoIs -> per-class NMS) on a
+2048x2048 synthetic tile (BASELINE config 3), stage by stage.  usage: python tools/predict_timing.py [img_size]"""
+import os, sys, time
 import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
+import torch
+from faster_rcnn import models as M, rpn
+from faster_rcnn.RADNet import RADNet
+from faster_rcnn.base_models import resnet50
+from faster_rcnn.config import Config
+from radnet_hip import synth
 
-from faster_rcnn import models  # noqa: E402
-from faster_rcnn.RADNet import RADNet  # noqa: E402
-from faster_rcnn.base_models import resnet50  # noqa: E402
-from faster_rcnn.config import Config  # noqa: E402
-from radnet_hip import synth  # noqa: E402
-
-
-def main():
-    C = Config()
-    if len(sys.argv) > 1:
-        C.img_size = int(sys.argv[1])
-    m_rpn, m_cls, m_all, m_rpn3, m_det = models.build_models(C)
-    m_all._s.eng.set_weights(synth.synthetic_weights(seed=3))
-    net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
-    net.bbox_threshold = 0.0          # synthetic weights are never confident: keep every non-background RoI in the tail
-    tile = np.random.RandomState(4).randint(0, 256, (2048, 2048, 3)).astype(np.uint8)
-    for _ in range(3):
-        dets = net.predict([tile])
-    torch.cuda.synchronize()
+C = Config(); C.img_size = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+m_rpn, m_cls, m_all, m_rpn3, m_det = M.build_models(C, weights=synth.synthetic_weights(seed=3))
+net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+tile = np.random.RandomState(4).randint(0, 256, (2048, 2048, 3)).astype(np.uint8)
+for _ in range(3):
+    net._detect(tile)
+torch.cuda.synchronize()
+acc = {}
+def T(label, t0):
+    torch.cuda.synchronize(); t = time.perf_counter(); acc[label] = acc.get(label, 0.0) + t - t0; return t
+n = 10
+t_all = time.perf_counter()
+for _ in range(n):
     t = time.perf_counter()
-    n = 10
-    for _ in range(n):
-        dets = net.predict([tile])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / n
-    print("RADNet.predict, 2048x2048 tile -> short side %d: %.1f ms per tile (%d detections)" % (C.img_size, dt * 1e3, len(dets)))
-    pr = cProfile.Profile()
-    pr.enable()
-    for _ in range(3):
-        net.predict([tile])
-    pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats("cumulative").print_stats(18)
-
-
-if __name__ == "__main__":
-    main()
+    X, ratio = net.format_img(tile); t = T("format_img (device bicubic resize + preprocess)", t)
+    Y1, Y2, F = m_rpn3.predict(X); t = T("model_rpn.predict (base + RPN, outputs to host)", t)
+    R = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7); t = T("rpn_to_roi", t)
+    R[:, 2] -= R[:, 0]; R[:, 3] -= R[:, 1]
+    bb, pp = net.apply_spatial_pyramid_pooling(R, F); t = T("apply_spatial_pyramid_pooling (detector on all RoIs + decode)", t)
+    for key in bb:
+        rpn.non_max_suppression_fast(np.array(bb[key]), np.array(pp[key]), overlap_thresh=0.2)
+    t = T("per-class NMS", t)
+tot = (time.perf_counter() - t_all) / n
+print("img_size %d: %.2f ms per tile (%.1f tiles/s), %d RoIs" % (C.img_size, tot * 1e3, 1 / tot, len(R)))
+for k, v in acc.items():
+    print("  %7.2f ms  %s" % (v / n * 1e3, k))
