@@ -32,6 +32,8 @@ def _spans(length, tile, step):
 
 class RADNet():
 
+    device_resident = True      # engine-backed models: keep tiles on the device between the stages (see _detect)
+
     def __init__(self, C, model_rpn, model_detector, preprocess_func):
         self.is_object_threshold = 0.5
         self.bbox_threshold = 0.7
@@ -46,8 +48,9 @@ class RADNet():
         """Back to source-image pixels: floor-division by the resize ratio, then round (RADNet.py:44-51)."""
         return tuple(int(round(v // ratio)) for v in (x1, y1, x2, y2))
 
-    def format_img_size(self, img):
-        """Short side -> C.img_size, long side truncated (RADNet.py:53-74); bicubic resize on the device."""
+    def format_img_size(self, img, keep_on_device=False):
+        """Short side -> C.img_size, long side truncated (RADNet.py:53-74); bicubic resize on the device.
+        keep_on_device: return the resized uint8 image as a device tensor (the device-resident tile path)."""
         side = float(self.C.img_size)
         height, width = img.shape[:2]
         if width <= height:
@@ -56,6 +59,8 @@ class RADNet():
         else:
             ratio = side / height
             new_w, new_h = int(ratio * width), int(side)
+        if keep_on_device:
+            return resize_cubic(img, new_w, new_h, to_host=False), ratio
         if (new_h, new_w) != (height, width):
             img = resize_cubic(img, new_w, new_h)
         return img, ratio
@@ -148,10 +153,18 @@ class RADNet():
 
     # ---- inference ---------------------------------------------------------------------------------------------------
     def _detect(self, img):
-        """One network pass on an image or tile: {class: (boxes in source px, probs)} after the per-class NMS 0.2."""
-        X, ratio = self.format_img(img)
-        Y1, Y2, F = self.model_rpn.predict(X)
-        R = rpn.rpn_to_roi(Y1, Y2, self.C, overlap_thresh=0.7)
+        """One network pass on an image or tile: {class: (boxes in source px, probs)} after the per-class NMS 0.2.
+        With the engine-backed models the tile stays on the device from the resize to the classifier outputs (resize ->
+        preprocess -> base -> RPN -> decode/sort/NMS -> RoI crop-resize -> classifier): PCIe carries the source tile in and
+        ~40 KB of proposals and class scores out.  `device_resident = False` forces the NumPy-facing calls the reference
+        makes (RADNet.py:540-560); both give the same detections (same kernels), tests compare them."""
+        if self.device_resident and hasattr(self.model_rpn, "propose_device"):
+            img_dev, ratio = self.format_img_size(img, keep_on_device=True)
+            R, F = self.model_rpn.propose_device(img_dev, overlap_thresh=0.7)
+        else:
+            X, ratio = self.format_img(img)
+            Y1, Y2, F = self.model_rpn.predict(X)
+            R = rpn.rpn_to_roi(Y1, Y2, self.C, overlap_thresh=0.7)
         R[:, 2] -= R[:, 0]
         R[:, 3] -= R[:, 1]
         bboxes, probs = self.apply_spatial_pyramid_pooling(R, F)
@@ -209,15 +222,18 @@ class RADNet():
         return self.predict([get_image(img_path, [t], random_type=False) for t in types])
 
 
-def resize_cubic(img, new_w, new_h):
-    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_CUBIC) on the device (uint8 HWC)."""
+def resize_cubic(img, new_w, new_h, to_host=True):
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_CUBIC) on the device (uint8 HWC).  to_host=False: the
+    result stays a device tensor (an image already at the target size is just uploaded)."""
     import torch
     from radnet_hip import runtime as rt
     ctx = rt.default_context()
     src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
+    if not to_host and (new_h, new_w) == tuple(img.shape[:2]):
+        return src
     dst = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
     ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], dst, new_h, new_w, img.shape[2])
-    return dst.cpu().numpy()
+    return dst if not to_host else dst.cpu().numpy()
 
 
 def load_radnet(config_path, device_index=0):

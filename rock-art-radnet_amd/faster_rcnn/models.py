@@ -48,6 +48,17 @@ class _Shared:
             self._x_key, self._bp, self._f_host = key, bp, None
         return self._bp
 
+    def base_from_u8(self, img_dev):
+        """Base features for a uint8 BGR HWC image that is ALREADY on the device at network size (RADNet's device-resident
+        tile path): preprocess kernel + base forward, nothing crosses PCIe."""
+        eng = self.eng
+        H, W = int(img_dev.shape[0]), int(img_dev.shape[1])
+        bp = eng._plan_base(1, H, W, 0)
+        eng.ctx.call("radnet_preprocess_bgr", img_dev, H, W, 4, bp["x"])
+        eng.base_forward(bp)
+        self._x_key, self._bp, self._f_host = None, bp, None
+        return bp
+
     def sync_weights_from_engine(self):
         self.W.update(self.eng.get_weights())
 
@@ -114,6 +125,19 @@ class RPNModel(_ModelBase):
         return out
 
     predict_on_batch = predict
+
+    def propose_device(self, img_dev, overlap_thresh=0.7, max_boxes=300):
+        """Device-resident twin of predict() + rpn.rpn_to_roi() for RADNet's tile path: uint8 BGR image on the device ->
+        proposals (n,4) int64 x1,y1,x2,y2 in feature-map units on the host (a few KB) and the plans that hold the feature
+        map on the device.  Same kernels as the NumPy-facing calls, so the same proposals."""
+        eng = self._s.eng
+        bp = self._s.base_from_u8(img_dev)
+        rp = eng.rpn_forward(bp)
+        R, Rn = eng.proposals(rp, overlap_thresh=overlap_thresh, max_boxes=max_boxes)
+        n = int(Rn.cpu()[0])
+        if n <= 0:
+            raise ValueError("rpn_to_roi: no valid box")        # the reference's failed tuple-unpack (rpn.py:164-172)
+        return R[:n].cpu().numpy(), bp
 
     def _targets(self, Y, rp):
         import torch
@@ -203,7 +227,10 @@ class DetectorModel(_ModelBase):
         import torch
         eng = self._s.eng
         F, rois = inputs
-        Fd, fh, fw = self._features(F)
+        if isinstance(F, dict) and "F" in F:                 # a base plan from RPNModel.propose_device: features on the device
+            Fd, fh, fw = F["F"], F["fh"], F["fw"]
+        else:
+            Fd, fh, fw = self._features(F)
         rois = np.asarray(rois, dtype=np.float32).reshape(-1, 4)
         hp = eng._plan_head(rois.shape[0], fh, fw, Fd)
         hp["rois"].copy_(torch.from_numpy(rois))

@@ -232,3 +232,32 @@ def test_cfg3_predict_tile_2048(models):
     assert isinstance(dets, list)
     for d in dets:
         assert set(d) == {"class", "prob", "x1", "y1", "x2", "y2"}
+
+
+def test_device_resident_detect_equals_numpy_facing_path(models):
+    """RADNet._detect keeps a tile on the device from the resize to the classifier outputs when the models are engine-backed;
+    forcing the NumPy-facing calls the reference makes (predict -> rpn_to_roi -> detector.predict) must give the very same
+    proposals, decoded boxes and scores: same kernels, only the PCIe round trips differ."""
+    from faster_rcnn import rpn
+    from faster_rcnn.RADNet import RADNet
+    from faster_rcnn.base_models import resnet50
+    C, P0, (m_rpn, m_cls, m_all, m_rpn3, m_det) = models
+    net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+    net.bbox_threshold = 0.0                                   # synthetic weights: keep every non-background RoI in the comparison
+    for shape in ((2048, 2048, 3), (300, 300, 3), (700, 1100, 3)):
+        tile = np.random.RandomState(sum(shape)).randint(0, 256, shape).astype(np.uint8)
+        # stage-wise: proposals
+        img_dev, ratio_d = net.format_img_size(tile, keep_on_device=True)
+        R_dev, F_dev = m_rpn3.propose_device(img_dev, overlap_thresh=0.7)
+        X, ratio_h = net.format_img(tile)
+        Y1, Y2, F = m_rpn3.predict(X)
+        R_host = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
+        assert ratio_d == ratio_h and np.array_equal(R_dev, R_host)
+        # end to end
+        net.device_resident = True
+        a = net._detect(tile)
+        net.device_resident = False
+        b = net._detect(tile)
+        assert a.keys() == b.keys() and len(a) > 0
+        for k in a:
+            assert a[k][0] == b[k][0] and np.array_equal(np.array(a[k][1]), np.array(b[k][1]))

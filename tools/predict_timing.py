@@ -37,3 +37,15 @@ tot = (time.perf_counter() - t_all) / n
 print("img_size %d: %.2f ms per tile (%.1f tiles/s), %d RoIs" % (C.img_size, tot * 1e3, 1 / tot, len(R)))
 for k, v in acc.items():
     print("  %7.2f ms  %s" % (v / n * 1e3, k))
+for mode in (False, True):
+    net.device_resident = mode
+    for _ in range(3):
+        net._detect(tile)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        net._detect(tile)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    print("RADNet._detect, %s: %.2f ms per tile (%.1f tiles/s, %.1f TFLOP/s algorithmic at %.0f GF)" % (
+        "device-resident" if mode else "NumPy-facing calls", dt * 1e3, 1 / dt, (58.95 + 15 * 29.29) / dt / 1e3 if C.img_size == 600 else float("nan"), 58.95 + 15 * 29.29))
