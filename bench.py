@@ -146,7 +146,7 @@ def main():
         class _Adapter:              # same calling convention as TrainStep for the loops below
             skipped_head_steps = property(lambda self: _ts.skipped_head_steps)
 
-            def step(self, batch, next_batch=None, after_next=None):
+            def step(self, batch, next_batch=None, after_next=None, upcoming=None):
                 return _ts.step(batch)
 
             def flush(self):
@@ -173,7 +173,7 @@ def main():
         torch.cuda.synchronize()
 
     for k in range(args.warmup):      # the pipeline drains at the end of the warm-up: nothing of the timed steps is enqueued early
-        ts.step(batch, next_batch=batch if k + 1 < args.warmup else None, after_next=batch if k + 2 < args.warmup else None)
+        ts.step(batch, upcoming=[batch] * min(3, args.warmup - 1 - k))
     ts.flush()
     barrier()
     # Everything long-lived exists now (plans, descriptors, graphs): collect once and move it to the permanent generation,
@@ -188,7 +188,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # the input pipeline knows the next batch: its label / base-forward phases are enqueued across the host sync
-        ts.step(batch, next_batch=batch if k + 1 < args.steps else None, after_next=batch if k + 2 < args.steps else None)
+        ts.step(batch, upcoming=[batch] * min(3, args.steps - 1 - k))
     ts.flush()                       # multi-GPU: the last step's deferred head update belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0

@@ -333,6 +333,8 @@ class FasterRCNNEngine:
     # (tools/winograd_timing.py: rpn_conv1 201 -> 119 us, res4x_2b 39 -> 34, res3x_2b 40 -> 37; stage 2 loses, the
     # trainable stage-5 convs would pay a filter transform per step).  Trainable layers re-transform after Adam.
     WINOGRAD_LAYERS = ("rpn_conv1",) + tuple("res%d%s_branch2b" % (st, bl) for st, bls in ((3, "abcd"), (4, "abcdef")) for bl in bls)
+    if os.environ.get("RADNET_WINOGRAD_EXTRA"):        # experiment knob: comma-separated layer names
+        WINOGRAD_LAYERS = WINOGRAD_LAYERS + tuple(os.environ["RADNET_WINOGRAD_EXTRA"].split(","))
 
     def _uses_winograd(self, c):
         return self.use_winograd and c.name in self.WINOGRAD_LAYERS and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0

@@ -55,7 +55,7 @@ def allreduce_grad_arena_start(flat, world, group=None):
 
 
 class TrainStep:
-    NBUF = 4        # buffer sets in rotation: batch i+2's forward passes must not wait for batch i-1's head phase
+    NBUF = 5        # buffer sets in rotation: this batch, up to three announced ones, one whose head phase may still run
 
     def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
         """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
@@ -178,25 +178,24 @@ class TrainStep:
             st["roi"].append((R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i)))
         mark("D: rpn re-predict + proposals + roi targets enqueued")
 
-    def step(self, batch, next_batch=None, after_next=None):
+    def step(self, batch, next_batch=None, after_next=None, upcoming=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
         width, height: source-frame size the boxes refer to}.  Losses of the step: self.losses().
 
-        next_batch / after_next (optional, what a prefetching data loader knows: the batches of the next two calls, which
-        must then pass these same objects) switch the PIPELINED mode on; flush() ends the run.  Three chains then share
-        the GPU, each on its own stream and context (engine lanes), working on consecutive batches:
-          side: labelling kernels, upload and frozen base forward of batch i+2 (i+1 without after_next), its RPN forward
-                once Adam #1 of the batch before it is enqueued
-          main: RPN backward, Adam #1, re-prediction, proposals and RoI labelling of batch i+1, as soon as batch i's RoI
-                class codes have reached the host
+        upcoming (optional, what a prefetching data loader knows: the batches of the next calls, in order -- up to three
+        are used; next_batch / after_next name the first two individually) switches the PIPELINED mode on; the next calls
+        must then pass these same objects, and flush() ends the run.  Three chains then share the GPU, each on its own
+        stream and context (engine lanes), working on consecutive batches:
+          side: a prefetch queue -- labelling kernels, upload and frozen base forward of every announced batch not yet
+                started (it depends on nothing but a free buffer set, so it is always there to fill idle CUs)
+          main: RPN forward, losses / backward, Adam #1, re-prediction, proposals and RoI labelling of batch i+1, as soon as
+                batch i's RoI class codes have reached the host
           head: RoI batch, classifier forward / backward, Adam #2 of batch i
         They touch disjoint trainable weights (the base is frozen, the RPN and the classifier have their own optimizers),
         so every value is computed from exactly the operands the one-after-the-other order would use; no GEMM of this
         network fills 256 CUs for its whole duration (tails, split-K reductions, the one-workgroup NMS), co-scheduled
-        chains fill those holes.  With after_next the base forward of a batch is enqueued a whole step before its RPN
-        phase needs it, so the host's one wait per step covers the RPN chain alone.  The host's order -- sample selection
-        of this batch, then subsampling of the next batch's anchors -- and with it the order of draws from NumPy's global
-        RNG is the reference's."""
+        chains fill those holes.  The host's order -- sample selection of this batch, then subsampling of the next
+        batch's anchors -- and with it the order of draws from NumPy's global RNG is the reference's."""
         eng = self.eng
         C = eng.C
         nloc = len(batch)
@@ -210,42 +209,36 @@ class TrainStep:
 
         mark("start")
         after = getattr(eng, "after", lambda ev: None)
-        pipelined = self.side_prefetch and next_batch is not None and not eng.ctx.timing_on
+        ahead = list(upcoming) if upcoming is not None else [b for b in (next_batch, after_next) if b is not None]
+        ahead = ahead[:self.NBUF - 2]                  # buffer sets: this batch, the announced ones, one being recycled
+        pipelined = self.side_prefetch and bool(ahead) and not eng.ctx.timing_on
         q = self._queue                                # states of the coming batches, in call order
         st = q.popleft() if q and q[0]["batch"] is batch else None
         if st is None:
             q.clear()                                  # not the announced batch: what was prepared is dropped
-            st = self._launch_ab(batch, self._next_slot())
-        after(st.get("done"))                          # main lane: forward passes enqueued on the side lane
+            st = self._launch_a(batch, self._next_slot())
         if "roi" not in st:                            # first step of a run, or the previous call was not pipelined
+            after(st.get("done"))
+            self._launch_b(st)
             self._rpn_phase(st, ntot, mark)
-        if q and q[0]["batch"] is not next_batch:
-            q.clear()
-        nxt = q[0] if q else None
-        if len(q) > 1 and q[1]["batch"] is not after_next:
-            q.pop()
-        late = None                                    # state whose RPN forward waits for Adam #1 of `nxt`
+        for j in range(len(q)):                        # announced batches must be the ones prepared, in order
+            if j >= len(ahead) or q[j]["batch"] is not ahead[j]:
+                while len(q) > j:
+                    q.pop()
+                break
         if pipelined:
-            def side_a(b):
-                slot = self._next_slot()
-                after(self._head_done.get(slot))       # the head phase that last read this buffer set's feature map
-                return self._launch_a(b, slot)
-
-            with eng.lane("side"):
-                if nxt is None:                        # start-up: nothing of the next batch is enqueued yet
-                    nxt = side_a(next_batch)
-                    after(st["adam1"])                 # its RPN forward reads the RPN weights Adam #1 of this batch wrote
-                    self._launch_b(nxt)
-                    nxt["done"] = eng.mark()
-                    q.append(nxt)
-                if after_next is not None and len(q) < 2:
-                    late = side_a(after_next)
-                    q.append(late)
+            with eng.lane("side"):                     # prefetch queue: labelling kernels, upload, frozen base forward
+                for j in range(len(q), len(ahead)):
+                    slot = self._next_slot()
+                    after(self._head_done.get(slot))   # the head phase that last read this buffer set's feature map
+                    nb = self._launch_a(ahead[j], slot)
+                    nb["done"] = eng.mark()
+                    q.append(nb)
         else:
             after(self._head_last)                     # the head phase below runs on the main lane
-            if next_batch is not None and nxt is None:
-                nxt = self._launch_ab(next_batch, self._next_slot())  # one lane: keeps the GPU busy across the sync below
-                q.append(nxt)
+            if ahead and not q:
+                q.append(self._launch_a(ahead[0], self._next_slot()))   # one lane: keeps the GPU busy across the sync below
+        nxt = q[0] if q else None
         mark("B: next batch's upload + base + rpn forward enqueued")
         # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
         picks = []
@@ -266,13 +259,9 @@ class TrainStep:
                                          keep=(cls >= 0).copy(), cls=cls.copy(), sel_kept=list(sel_k)))
         # ---- pipelined: the next batch's RPN phase goes first -- the host sync of the NEXT call waits for it
         if pipelined:
-            after(nxt["done"])
+            after(nxt["done"])                         # its base forward was enqueued on the side lane a step or more ago
+            self._launch_b(nxt)                        # RPN forward with the weights Adam #1 of this batch wrote
             self._rpn_phase(nxt, ntot, mark)
-            if late is not None:
-                with eng.lane("side"):
-                    after(nxt["adam1"])
-                    self._launch_b(late)
-                    late["done"] = eng.mark()
         # ---- phase D, device half: classifier train step
         head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
         slot = st["slot"]
