@@ -126,10 +126,8 @@ class FasterRCNNEngine:
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
         self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
-        # second context on a side stream: with RADNET_OVERLAP_WGRAD=1 the weight-gradient GEMMs of a backward program
-        # run there, beside the dgrad chain they hang off (they only feed the optimizer).  Measured on MI355X at
-        # 1000x600: 3.48 ms/step with the overlap, 3.41 without -- each GEMM is tuned (tile, K slices) to fill the
-        # chip alone, and two of them in flight only compete for LDS / L2.  Kept as an option, off by default.
+        # Lanes: further contexts on their own streams (TrainStep's pipelined step, see lane()).  (Forking only the wgrad
+        # GEMMs of a backward program to a second stream was measured too: 3.48 ms/step against 3.41 on one stream.)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.use_copy_stream = os.environ.get("RADNET_NO_COPY_STREAM", "0") != "1"
         self.side_stream = torch.cuda.Stream(device=self.dev)
@@ -137,7 +135,6 @@ class FasterRCNNEngine:
         self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
         self.ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
         self.ctx2.check(self.lib.radnet_set_workspace(self.ctx2.h, self.ws2.data_ptr(), self.ws2.numel()), "set_workspace")
-        self.overlap_wgrad = os.environ.get("RADNET_OVERLAP_WGRAD", "0") == "1"
         self.head_stream = torch.cuda.Stream(device=self.dev)
         self.ctx3 = L.Context(device_index, stream_handle=self.head_stream.cuda_stream)
         self.ctx3.check(self.lib.radnet_set_autotune(self.ctx3.h, 1 if autotune else 0), "set_autotune")
@@ -446,21 +443,20 @@ class FasterRCNNEngine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def _run(self, ops, overlap=False):
-        """Run a layer program (overlap: its wgrad launches go to the side stream, see __init__).  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
+    def _run(self, ops):
+        """Run a layer program on the current lane.  Programs are static (fixed buffers, fixed descriptors), so after one eager run -- which
         autotunes every new GEMM shape and builds its work-unit tables -- the launch sequence is recorded into a
         hipGraph and replayed: ~20 us of host time per launch (ctypes + hipLaunchKernel) become one graph launch, and
         the host thread stays ahead of the GPU (tools/host_timeline.py).  Keyed by the program and the gradient
         write modes of its wgrad descriptors (set_accumulate edits them in place)."""
-        overlap = overlap and self.overlap_wgrad and not self.ctx.timing_on      # timed launches run one at a time
-        key = (id(ops), id(self.ctx), overlap, tuple(p.dw_accumulate if kind == "wgrad" else p[-1] for kind, p in ops if kind in ("wgrad", "wino_wgrad")))
+        key = (id(ops), id(self.ctx), tuple(p.dw_accumulate if kind == "wgrad" else p[-1] for kind, p in ops if kind in ("wgrad", "wino_wgrad")))
         ent = self._graphs.get(key)
         if ent is None:
             # first run of this program: every new GEMM shape is measured here, so launches run one at a time
             self._graphs[key] = [ops, None]          # holds `ops` so its id stays unique
-            return self._run_eager(ops, overlap, isolate=True)
+            return self._run_eager(ops)
         if not self.use_graphs or self.ctx.timing_on or torch.cuda.is_current_stream_capturing():
-            return self._run_eager(ops, overlap)
+            return self._run_eager(ops)
         if ent[1] is None:
             g = torch.cuda.CUDAGraph()
             prev = self.ctx.stream_handle
@@ -470,7 +466,7 @@ class FasterRCNNEngine:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
                     try:
-                        self._run_eager(ops, overlap)
+                        self._run_eager(ops)
                     finally:
                         self.ctx.set_stream(prev)
                 ent[1] = g
@@ -479,31 +475,16 @@ class FasterRCNNEngine:
                 sys.stderr.write("radnet: hipGraph capture failed (%s); layer programs run eagerly\n" % (e,))
                 self.ctx.set_stream(prev)
                 self.use_graphs = False
-                return self._run_eager(ops, overlap)
+                return self._run_eager(ops)
         ent[1].replay()
 
-    def _run_eager(self, ops, overlap=False, isolate=False):
+    def _run_eager(self, ops):
         lib, h = self.lib, self.ctx.h
-        forked = False
         for kind, p in ops:
             if kind == "conv":
                 rc = lib.radnet_conv_fwd(h, C.byref(p))
             elif kind == "dgrad":
                 rc = lib.radnet_conv_dgrad(h, C.byref(p))
-            elif kind == "wgrad" and overlap:
-                # everything enqueued so far on the main stream produced this launch's inputs; gradient buffers are
-                # written once per backward pass, so nothing the main stream does later can overwrite them
-                ev = torch.cuda.Event()
-                ev.record()
-                self.side_stream.wait_event(ev)
-                if isolate:
-                    torch.cuda.current_stream().synchronize()
-                rc = lib.radnet_conv_wgrad(self.ctx2.h, C.byref(p))
-                if rc != 0:
-                    self.ctx2.check(rc, kind)
-                if isolate:
-                    self.side_stream.synchronize()
-                forked = True
             elif kind == "wgrad":
                 rc = lib.radnet_conv_wgrad(h, C.byref(p))
             elif kind == "maxpool":
@@ -567,8 +548,6 @@ class FasterRCNNEngine:
                 raise L.RadnetError("unknown op " + kind)
             if rc != 0:
                 self.ctx.check(rc, kind)
-        if forked:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     @staticmethod
     def _fuse_bias_grads(ops):
@@ -702,7 +681,7 @@ class FasterRCNNEngine:
         """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
         self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,
                       self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
-        self._run(rp["bwd"], overlap=True)
+        self._run(rp["bwd"])
 
     def adam(self, arena, grad_scale=1.0, zero_grad=True):
         """One Keras-2 Adam step over the arena.  zero_grad: the gradient arena is cleared in the same pass, so the
@@ -860,10 +839,10 @@ class FasterRCNNEngine:
                       self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
         if on_part is None or "bwd_parts" not in hp:
-            self._run(hp["bwd"], overlap=True)
+            self._run(hp["bwd"])
             return
         for part, (lo, hi) in hp["bwd_parts"]:
-            self._run(part, overlap=True)
+            self._run(part)
             on_part(lo, hi)
 
     # ------------------------------------------------------------------------------------------ targets
