@@ -99,6 +99,9 @@ __device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned 
   f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ float buf_load1s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
+}
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int2 buf_load2i(__amdgpu_buffer_rsrc_t r, unsigned off) {
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
@@ -665,14 +668,20 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
             }
     }
   }
-  // Branch-free like the operand loads: rows past M / columns past N get the offset kOOB, which the hardware answers
-  // with 0 for loads and drops for stores.  All 16 residual (and mask) loads of a 32x32 tile are issued back to back
-  // before the first store, so their latency is paid once per tile instead of once per register (a conditional
-  // load -> store chain cannot be reordered by the compiler: y may alias the addend).
+  // Branch-free like the operand loads, and with the same split of the address: per lane ONE offset per 32x32 tile (its
+  // column in the tile's first row, kOOB for a column past N or a wave that holds no output), the row of accumulator
+  // register r -- (r&3) + 8*(r>>2) rows further down -- in the SGPR offset.  Rows past M need no test: the descriptors end
+  // with row M-1 (y_bytes = ((M-1)*ld + N)*4), the hardware drops the store / answers the load with 0.  Only the LOADS use
+  // the SGPR operand: buffer stores with a non-zero SGPR offset ran the whole kernel at HALF speed on gfx950 (measured,
+  // tools/concurrency_probe.py: 66 -> 33 TFLOP/s on a 1x1 layer), so the stores add the row offset in a VGPR.  All 16 residual
+  // (and mask) loads of a 32x32 tile are issued back to back before the first store, so their latency is paid once per
+  // tile instead of once per register (a conditional load -> store chain cannot be reordered by the compiler: y may
+  // alias the addend).
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(g.y + bz * g.y_bstride, g.y_bytes);
   const __amdgpu_buffer_rsrc_t radd = make_rsrc(g.addend, g.addend ? g.add_bytes : 0u);     // null -> every load returns 0
   const __amdgpu_buffer_rsrc_t rmask = make_rsrc(g.mask, g.mask ? g.mask_bytes : 0u);
   const bool has_mask = g.mask != nullptr;
+  const unsigned ldy4 = (unsigned)g.ldy * 4u, lda4 = (unsigned)g.ld_add * 4u, ldm4 = (unsigned)g.ld_mask * 4u;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -685,24 +694,26 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * hi;
+      const bool col_ok = live_out & nv & (mb < g.M);        // mb >= M: every row of this lane is past the end
+      const unsigned vy = col_ok ? ((unsigned)mb * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB;
+      const unsigned va = col_ok ? ((unsigned)mb * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB;
+      const unsigned vm = col_ok ? ((unsigned)mb * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB;
       float ad[16], mk[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        const bool ok = live_out & nv & (m < g.M);
-        ad[r] = buf_load1(radd, ok ? ((unsigned)m * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB);
+        const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
+        ad[r] = buf_load1s(radd, va, row * lda4);
         mk[r] = 1.f;
-        if (has_mask) mk[r] = buf_load1(rmask, ok ? ((unsigned)m * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB);
+        if (has_mask) mk[r] = buf_load1s(rmask, vm, row * ldm4);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        const bool ok = live_out & nv & (m < g.M);
+        const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
         float v = acc[i][j][r] * sc + sh + ad[r];
         if (!(mk[r] > 0.f)) v = 0.f;
         if (g.act == 1) v = fmaxf(v, 0.f);
         else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
-        buf_store1(ry, ok ? ((unsigned)m * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB, v);
+        buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
       }
     }
   }
