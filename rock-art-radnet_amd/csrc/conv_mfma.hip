@@ -1090,7 +1090,9 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   {
     const uint64_t xb = (uint64_t)(g.M / g.OHOW) * g.H * g.W * g.C * 4ull;      // images * H * W * C floats
     const uint64_t wb = (bmode == 0) ? (uint64_t)g.K * g.ldw * 4ull : (uint64_t)g.npos * g.cin_fwd * g.ldw * 4ull;
-    if (xb >= (1ull << 31) || wb >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: tensor larger than 2 GiB");
+    // x is addressed through a descriptor that starts one halo (pad_t rows + pad_l pixels) early: that too stays below 2^31
+    const uint64_t halo = ((uint64_t)g.pad_t * g.W + g.pad_l) * g.C * 4ull;
+    if (xb + halo >= (1ull << 31) || wb >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: tensor larger than 2 GiB");
     g.x_bytes = (unsigned)xb;
     g.w_bytes = (unsigned)wb;
     const uint64_t ld_max = (uint64_t)std::max(g.ldy, std::max(g.addend ? g.ld_add : 0, g.mask ? g.ld_mask : 0));
@@ -1280,7 +1282,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   g.x_bias = (unsigned)(((int64_t)d->pad_t * d->w_ + d->pad_l) * d->c * 4);
   {
     const uint64_t xb = (uint64_t)d->nb * d->h * d->w_ * d->c * 4ull, db = (uint64_t)g.M * g.ld_dy * 4ull;
-    if (xb >= (1ull << 31) || db >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: tensor larger than 2 GiB");
+    if (xb + g.x_bias >= (1ull << 31) || db >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: tensor larger than 2 GiB");
     g.x_bytes = (unsigned)xb;
     g.dy_bytes = (unsigned)db;
   }
