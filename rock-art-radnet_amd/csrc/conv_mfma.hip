@@ -701,6 +701,9 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
       float ad[16], mk[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef RADNET_DIAG_SKIP_EPILOGUE                 // measurement only: 1 of 16 rows is loaded / stored
+        if (r != 0) { ad[r] = 0.f; mk[r] = 1.f; continue; }
+#endif
         const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
         ad[r] = buf_load1s(radd, va, row * lda4);
         mk[r] = 1.f;
@@ -713,6 +716,9 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
         if (!(mk[r] > 0.f)) v = 0.f;
         if (g.act == 1) v = fmaxf(v, 0.f);
         else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
+#ifdef RADNET_DIAG_SKIP_EPILOGUE
+        if (r != 0) { asm volatile("" ::"v"(v)); continue; }
+#endif
         buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
       }
     }
