@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Per-stream view of a rocprofv3 --kernel-trace CSV for one steady-state train step: busy time per queue/stream, the
 union of busy intervals, and the kernel sequence with start offsets (to see which lane waits for which).
-usage: lane_timeline.py <kernel_trace.csv> [n_rows_to_print]"""
+usage: lane_timeline.py <kernel_trace.csv> [n_rows_to_print] [adam launches to skip from the end (default 40: clear of the run's drain phase)]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 lane_key = 'Stream_Id' if 'Stream_Id' in rows[0] else 'Queue_Id'
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-s, e = idx[-9] + 1, idx[-5] + 1          # two steady-state steps (two Adam launches each)
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+s, e = idx[-skip - 5] + 1, idx[-skip - 1] + 1          # two steady-state steps (two Adam launches each)
 seg = rows[s:e]
 t0 = int(seg[0]['Start_Timestamp'])
 def short(n):
