@@ -141,11 +141,23 @@ class FasterRCNNEngine:
         self.ws3 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
         self.ctx3.check(self.lib.radnet_set_workspace(self.ctx3.h, self.ws3.data_ptr(), self.ws3.numel()), "set_workspace")
         self._lanes = {"side": (self.ctx2, self.side_stream), "head": (self.ctx3, self.head_stream)}
+        # further prefetch lanes: base forwards of different batches are independent GEMM chains, and the chip packs several
+        # of them better than one (tools/concurrency_probe.py); TrainStep deals announced batches over them round-robin
+        self.n_side_lanes = max(1, int(os.environ.get("RADNET_SIDE_LANES", "2")))
+        self._extra_lanes = []
+        for k in range(1, self.n_side_lanes):
+            st = torch.cuda.Stream(device=self.dev)
+            cx = L.Context(device_index, stream_handle=st.cuda_stream)
+            cx.check(self.lib.radnet_set_autotune(cx.h, 1 if autotune else 0), "set_autotune")
+            ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
+            cx.check(self.lib.radnet_set_workspace(cx.h, ws.data_ptr(), ws.numel()), "set_workspace")
+            self._extra_lanes.append((st, cx, ws))
+            self._lanes["side%d" % k] = (cx, st)
         if os.environ.get("RADNET_FORCE_CONFIG"):      # experiment: "tile_a,tile_b,slices" for every GEMM launch of every lane
             fa, fb, fs = (int(v) for v in os.environ["RADNET_FORCE_CONFIG"].split(","))
-            for c in (self.ctx, self.ctx2, self.ctx3):
+            for c in [self.ctx, self.ctx2, self.ctx3] + [e[1] for e in self._extra_lanes]:
                 c.check(self.lib.radnet_force_config(c.h, fa, fb, fs), "force_config")
-        for c in (self.ctx2, self.ctx3):           # one table of measured launch choices for all lanes
+        for c in [self.ctx2, self.ctx3] + [e[1] for e in self._extra_lanes]:           # one table of measured launch choices for all lanes
             self.ctx.check(self.lib.radnet_share_tuning(c.h, self.ctx.h), "share_tuning")
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)

@@ -227,9 +227,10 @@ class TrainStep:
                     q.pop()
                 break
         if pipelined:
-            with eng.lane("side"):                     # prefetch queue: labelling kernels, upload, frozen base forward
-                for j in range(len(q), len(ahead)):
-                    slot = self._next_slot()
+            for j in range(len(q), len(ahead)):        # prefetch queue: labelling kernels, upload, frozen base forward
+                slot = self._next_slot()
+                k = self._slots % getattr(eng, "n_side_lanes", 1)      # announced batches go round-robin over the prefetch lanes
+                with eng.lane("side%d" % k if k else "side"):
                     after(self._head_done.get(slot))   # the head phase that last read this buffer set's feature map
                     nb = self._launch_a(ahead[j], slot)
                     nb["done"] = eng.mark()
