@@ -55,7 +55,8 @@ def allreduce_grad_arena_start(flat, world, group=None):
 
 
 class TrainStep:
-    NBUF = 5        # buffer sets in rotation: this batch, up to three announced ones, one whose head phase may still run
+    NBUF = 6        # buffer sets in rotation: this batch, up to three announced ones, whose head phase may still run; even,
+                    # so that the sets alternate between the two prefetch lanes
 
     def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
         """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
@@ -210,7 +211,7 @@ class TrainStep:
         mark("start")
         after = getattr(eng, "after", lambda ev: None)
         ahead = list(upcoming) if upcoming is not None else [b for b in (next_batch, after_next) if b is not None]
-        ahead = ahead[:self.NBUF - 2]                  # buffer sets: this batch, the announced ones, one being recycled
+        ahead = ahead[:3]                              # lookahead; NBUF - 3 further sets cover head phases still in flight
         pipelined = self.side_prefetch and bool(ahead) and not eng.ctx.timing_on
         q = self._queue                                # states of the coming batches, in call order
         st = q.popleft() if q and q[0]["batch"] is batch else None
@@ -229,8 +230,8 @@ class TrainStep:
         if pipelined:
             for j in range(len(q), len(ahead)):        # prefetch queue: labelling kernels, upload, frozen base forward
                 slot = self._next_slot()
-                k = self._slots % getattr(eng, "n_side_lanes", 1)      # announced batches go round-robin over the prefetch lanes
-                with eng.lane("side%d" % k if k else "side"):
+                k = slot % getattr(eng, "n_side_lanes", 1)   # consecutive batches alternate lanes; a buffer set keeps its lane
+                with eng.lane("side%d" % k if k else "side"):   # (and with it its context: one graph per program)
                     after(self._head_done.get(slot))   # the head phase that last read this buffer set's feature map
                     nb = self._launch_a(ahead[j], slot)
                     nb["done"] = eng.mark()
