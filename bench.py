@@ -21,7 +21,7 @@ for _p in (ROOT, os.path.join(ROOT, "rock-art-radnet_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-# The step keeps 4 HIP streams busy (three lanes + the upload stream) and RCCL adds one per communicator; HIP multiplexes
+# The step keeps 4 HIP streams busy (main, two prefetch lanes, head lane) and RCCL adds one per communicator; HIP multiplexes
 # streams over 4 hardware queues by default, and two busy streams that land on one queue serialise (measured: the
 # pipelined step 385 instead of 441 images/s once RCCL's streams exist).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -210,6 +210,14 @@ def main():
     # ---- roofline leg: same step, GEMM launches bracketed by HIP events on the launch stream (not inside `value`)
     roof = None
     if args.roofline_steps > 0:
+        # The leg runs the step on ONE lane (launches alone on the chip).  The pipelined run above kept the head phase on
+        # its own context: give the main context its work-unit / row tables for those shapes first (built on first use with
+        # a host-synchronous upload that would otherwise sit between a launch's two events).
+        for _ in range(6):          # every buffer set once
+            ts.step(batch)
+        torch.cuda.synchronize()
+        if os.environ.get("RADNET_ROOFLINE_SLEEP"):      # experiment knob
+            time.sleep(float(os.environ["RADNET_ROOFLINE_SLEEP"]))
         eng.ctx.timing(True)
         eng.ctx.timing_reset()
         eng.wino_timing[:] = [0.0, 0.0, 0]

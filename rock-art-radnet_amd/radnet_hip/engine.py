@@ -128,8 +128,11 @@ class FasterRCNNEngine:
         self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
         # Lanes: further contexts on their own streams (TrainStep's pipelined step, see lane()).  (Forking only the wgrad
         # GEMMs of a backward program to a second stream was measured too: 3.48 ms/step against 3.41 on one stream.)
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
-        self.use_copy_stream = os.environ.get("RADNET_NO_COPY_STREAM", "0") != "1"
+        # A separate upload stream is OFF by default: with the lanes in place the upload already runs on a prefetch lane,
+        # off every critical chain, and one more busy HIP stream made the mapping of streams to hardware queues erratic
+        # (same code 181 ... 480 images/s depending on how many streams existed).  RADNET_COPY_STREAM=1 enables it.
+        self.use_copy_stream = os.environ.get("RADNET_COPY_STREAM", "0") == "1"
+        self.copy_stream = torch.cuda.Stream(device=self.dev) if self.use_copy_stream else None
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self.ctx2 = L.Context(device_index, stream_handle=self.side_stream.cuda_stream)
         self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
