@@ -250,10 +250,12 @@ def test_cfg4_two_images_per_step_vs_oracle():
             assert np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
 
 
-def test_prefetched_next_batch_equals_back_to_back_steps():
-    """TrainStep.step(batch, next_batch=...) enqueues the next batch's labelling / base / RPN forward across the host
-    sync of the current step.  Same arithmetic, same order of NumPy RNG draws: three steps with the prefetch must equal
-    three back-to-back steps (up to the fp32 atomics of split wgrad launches)."""
+@pytest.mark.parametrize("n_steps,lookahead", [(3, 1), (7, 3)])
+def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead):
+    """The pipelined step (TrainStep.step(batch, upcoming=[...]): prefetch lanes for the announced batches' base forward, the
+    next batch's RPN phase ahead of this batch's head phase, head phase on its own lane -- what bench.py runs) against
+    back-to-back steps on one lane.  Same arithmetic, same order of NumPy RNG draws: losses, weights and RNG consumption
+    must agree (up to the fp32 atomics of split wgrad launches).  (7, 3): more batches than buffer sets, full lookahead."""
     from faster_rcnn.config import Config
     from oracle import dense
     from radnet_hip import synth
@@ -263,7 +265,7 @@ def test_prefetched_next_batch_equals_back_to_back_steps():
     C.img_size = 300
     P = dense.init_params(seed=3)
     batches = []
-    for i in range(3):
+    for i in range(n_steps):
         meta = synth.synthetic_gt(40 + i, n=6, src_w=1000, src_h=600, smin=60, smax=300)
         batches.append([dict(img=synth.synthetic_panel(30 + i, 300, 500), bboxes=meta["bboxes"], width=1000, height=600)])
     results = []
@@ -277,8 +279,9 @@ def test_prefetched_next_batch_equals_back_to_back_steps():
         ts = TrainStep(eng)
         losses = []
         for k, b in enumerate(batches):
-            ts.step(b, next_batch=batches[k + 1] if prefetch and k + 1 < len(batches) else None)
+            ts.step(b, upcoming=batches[k + 1:k + 1 + lookahead] if prefetch else None)
             losses.append(ts.losses())
+        ts.flush()
         results.append((losses, eng.get_weights(), np.random.randint(0, 2 ** 31 - 1)))
         if tune is None:
             import tempfile
