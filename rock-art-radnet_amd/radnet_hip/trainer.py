@@ -241,6 +241,12 @@ class TrainStep:
             if ahead and not q:
                 q.append(self._launch_a(ahead[0], self._next_slot()))   # one lane: keeps the GPU busy across the sync below
         nxt = q[0] if q else None
+        if pipelined and nxt.get("rps") is None:
+            # The next batch's RPN forward needs only its base forward and the RPN weights of Adam #1 of THIS batch, both
+            # enqueued long ago: it goes to the main lane now, ahead of the host's wait below, and is off the cycle
+            # "RoI codes -> sample selection -> anchor subsampling -> RPN backward ... -> RoI codes" that bounds the step.
+            after(nxt["done"])
+            self._launch_b(nxt)
         mark("B: next batch's upload + base + rpn forward enqueued")
         # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
         picks = []
@@ -261,9 +267,7 @@ class TrainStep:
                                          keep=(cls >= 0).copy(), cls=cls.copy(), sel_kept=list(sel_k)))
         # ---- pipelined: the next batch's RPN phase goes first -- the host sync of the NEXT call waits for it
         if pipelined:
-            after(nxt["done"])                         # its base forward was enqueued on the side lane a step or more ago
-            self._launch_b(nxt)                        # RPN forward with the weights Adam #1 of this batch wrote
-            self._rpn_phase(nxt, ntot, mark)
+            self._rpn_phase(nxt, ntot, mark)           # its RPN forward is already enqueued (above)
         # ---- phase D, device half: classifier train step
         head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
         slot = st["slot"]
