@@ -216,7 +216,11 @@ class TrainStep:
         q = self._queue                                # states of the coming batches, in call order
         st = q.popleft() if q and q[0]["batch"] is batch else None
         if st is None:
-            q.clear()                                  # not the announced batch: what was prepared is dropped
+            if q and "roi" in q[0]:
+                # the announced batch's RPN phase -- an optimizer step -- has already been applied: dropping it silently would
+                # train the RPN on a batch whose classifier step never happens
+                raise RuntimeError("TrainStep.step: the previous call announced a different next batch (pass the same object)")
+            q.clear()                                  # not the announced batch: forward passes prepared for it are dropped
             st = self._launch_a(batch, self._next_slot())
         if "roi" not in st:                            # first step of a run, or the previous call was not pipelined
             after(st.get("done"))

@@ -296,3 +296,28 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead):
     for name in ("rpn_conv1", "rpn_out_class", "res5a_branch2a", "res5c_branch2c", "dense_class_7"):
         for k in ("kernel", "bias"):
             assert np.allclose(w0[name][k], w1[name][k], rtol=0, atol=2e-7), (name, k)
+
+
+def test_changed_announcement_is_refused():
+    """A pipelined step applies the announced batch's RPN phase (an optimizer step) ahead of time: the next call must bring
+    that batch."""
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size = 300
+    eng = FasterRCNNEngine(C)
+    eng.set_weights(dense.init_params(seed=3))
+    np.random.seed(64)
+    mk = lambda i: [dict(img=synth.synthetic_panel(30 + i, 300, 500), width=1000, height=600,
+                         bboxes=synth.synthetic_gt(40 + i, n=6, src_w=1000, src_h=600, smin=60, smax=300)["bboxes"])]
+    b0, b1, b2 = mk(0), mk(1), mk(2)
+    ts = TrainStep(eng)
+    ts.step(b0, upcoming=[b1])
+    with pytest.raises(RuntimeError):
+        ts.step(b2)
+    ts.step(b1)                                  # the announced batch is still accepted
+    ts.flush()
+    assert ts.losses()["n_head"] == 1
