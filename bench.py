@@ -260,7 +260,11 @@ def main():
                                    "batch=%d per GPU, %s" % (args.width, args.height, args.per_gpu_batch,
                                                               "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
                        "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
-                       "parallelism": "dp%d" % world, "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
+                       "parallelism": "dp%d" % world,
+                       "schedule": ("one lane" if cont or not getattr(ts, "side_prefetch", False) else
+                                    "pipelined over HIP streams: %d prefetch lanes (base forward, 3 batches ahead), RPN phase, head phase"
+                                    % getattr(eng, "n_side_lanes", 1)),
+                       "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
                        "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},
             "losses": losses,
         }
