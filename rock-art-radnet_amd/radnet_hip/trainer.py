@@ -81,6 +81,7 @@ class TrainStep:
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self._head_done = {}             # buffer set -> event: end of the head phase that last read its feature map
         self._head_last = None           # event: end of the last head phase enqueued on the head lane
+        self._lane_mode = False          # True between the first pipelined call and flush()
         self._queue = collections.deque()    # states of the announced batches, enqueued ahead (step(next_batch=...))
         self._slots = 0                  # batches started: buffer set = count % NBUF
         # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
@@ -113,6 +114,7 @@ class TrainStep:
         if self._head_last is not None:
             self.eng.after(self._head_last)
             self._head_last = None
+        self._lane_mode = False
         self._finish_head_update()
 
     def _gt(self, s):
@@ -213,6 +215,10 @@ class TrainStep:
         ahead = list(upcoming) if upcoming is not None else [b for b in (next_batch, after_next) if b is not None]
         ahead = ahead[:3]                              # lookahead; NBUF - 3 further sets cover head phases still in flight
         pipelined = self.side_prefetch and bool(ahead) and not eng.ctx.timing_on
+        # lane mode: from the first pipelined call until flush().  Base forwards and head phases then stay on their lanes
+        # (contexts, recorded graphs) also in the calls that announce nothing -- the first and the last step of a run
+        lanes = self.side_prefetch and not eng.ctx.timing_on and (pipelined or self._lane_mode)
+        self._lane_mode = lanes
         q = self._queue                                # states of the coming batches, in call order
         st = q.popleft() if q and q[0]["batch"] is batch else None
         if st is None:
@@ -221,7 +227,15 @@ class TrainStep:
                 # train the RPN on a batch whose classifier step never happens
                 raise RuntimeError("TrainStep.step: the previous call announced a different next batch (pass the same object)")
             q.clear()                                  # not the announced batch: forward passes prepared for it are dropped
-            st = self._launch_a(batch, self._next_slot())
+            slot = self._next_slot()
+            if lanes:
+                k = slot % getattr(eng, "n_side_lanes", 1)
+                with eng.lane("side%d" % k if k else "side"):
+                    after(self._head_done.get(slot))
+                    st = self._launch_a(batch, slot)
+                    st["done"] = eng.mark()
+            else:
+                st = self._launch_a(batch, slot)
         if "roi" not in st:                            # first step of a run, or the previous call was not pipelined
             after(st.get("done"))
             self._launch_b(st)
@@ -240,7 +254,7 @@ class TrainStep:
                     nb = self._launch_a(ahead[j], slot)
                     nb["done"] = eng.mark()
                     q.append(nb)
-        else:
+        elif not lanes:
             after(self._head_last)                     # the head phase below runs on the main lane
             if ahead and not q:
                 q.append(self._launch_a(ahead[0], self._next_slot()))   # one lane: keeps the GPU busy across the sync below
@@ -273,7 +287,7 @@ class TrainStep:
         if pipelined:
             self._rpn_phase(nxt, ntot, mark)           # its RPN forward is already enqueued (above)
         # ---- phase D, device half: classifier train step
-        head_lane = (lambda: eng.lane("head")) if pipelined else contextlib.nullcontext
+        head_lane = (lambda: eng.lane("head")) if lanes else contextlib.nullcontext
         slot = st["slot"]
         n_head = 0
         live = [i for i in range(nloc) if picks[i] is not None]
@@ -315,7 +329,7 @@ class TrainStep:
                     self._allreduce(eng.head_arena)
                     eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
                     eng.refresh_head_shift()
-            if pipelined:
+            if lanes:
                 self._head_last = self._head_done[slot] = eng.mark()
         mark("D: head forward + backward + adam enqueued")
         self.last = (nloc, n_head, slot)
