@@ -1,0 +1,186 @@
+"""Host data feed for the train step: the input side of utils.get_tile_generator (utils.py:310-552)
+without its label computation -- tiles, class balancing, box clipping, resize -- yielding the samples
+`radnet_hip.trainer.TrainStep.step` takes ({img: uint8 BGR at network size, bboxes, width, height}); the anchor labels
+the reference computes inside its generator (calc_region_props) are computed on the device by the step itself.
+
+Same control flow and the same draws from the random stream as the reference, in the same order:
+  np.random.shuffle(data) per epoch (train mode); per image the class-balance test; the tile grid; per tile
+  [np.random.choice over the image types when C.use_img_type] -> np.random.randint(0, #tiles left) -> clip boxes to the
+  tile (drop those left with less than C.tile_bbox_clip_threshold of their area) -> tile coordinates (int / ceil) ->
+  skip empty tiles and tiles without the class whose turn it is -> resize to get_new_img_size (bicubic, on the device);
+  then the full image when C.include_full_img.
+Augmentation (augmentation.py:85-533) is not built: in train mode every C.use_* augmentation switch must
+be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
+HWC`): OpenCV, which the reference decodes with, is not part of this build.
+
+rng: None = NumPy's global stream, i.e. exactly the reference's interleaving with the step's own draws when samples are
+pulled one per step; pass a RandomState to pull samples AHEAD of the step (TrainStep's `upcoming` lookahead) without
+disturbing the global stream the step draws from -- the tile choices then come from that private stream.
+"""
+import copy
+import itertools
+import math
+
+import numpy as np
+
+from .utils import get_new_img_size
+
+AUGMENT_SWITCHES = ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear",
+                    "use_brightness", "use_noise")          # augmentation.py:495-518
+
+
+class SampleSelector:
+    """utils.py:19-59: cycle through the classes that occur; an image is skipped unless it holds the class whose turn it
+    is, a tile likewise -- and a tile that does hold it advances the turn."""
+
+    def __init__(self, class_count):
+        self.classes = [c for c in class_count.keys() if class_count[c] > 0]
+        self.class_cycle = itertools.cycle(self.classes)
+        self.curr_class = next(self.class_cycle)
+
+    def _has_current(self, img_data):
+        return any(b["class"] == self.curr_class for b in img_data["bboxes"])
+
+    def skip_image_for_balanced_class(self, img_data):
+        return not self._has_current(img_data)
+
+    def skip_tile_for_balanced_class(self, img_data):
+        if self._has_current(img_data):
+            self.curr_class = next(self.class_cycle)
+            return False
+        return True
+
+
+def clip_box(bbox, img_box, alpha):
+    """augmentation.py:33-83: clip (N, 4+) boxes x1 y1 x2 y2 to img_box; keep a box iff it touches the image box and loses
+    less than (1 - alpha) of its area.  Returns (clipped boxes that are kept, keep mask over the input)."""
+    bbox = np.asarray(bbox)
+    x1, y1, x2, y2 = img_box[0], img_box[1], img_box[2], img_box[3]
+    outside = (bbox[:, 0] > x2) | (bbox[:, 2] < x1) | (bbox[:, 1] > y2) | (bbox[:, 3] < y1)
+    area = (bbox[:, 2] - bbox[:, 0]) * (bbox[:, 3] - bbox[:, 1])
+    clipped = np.hstack((np.maximum(bbox[:, 0], x1).reshape(-1, 1), np.maximum(bbox[:, 1], y1).reshape(-1, 1),
+                         np.minimum(bbox[:, 2], x2).reshape(-1, 1), np.minimum(bbox[:, 3], y2).reshape(-1, 1), bbox[:, 4:]))
+    lost = (area - (clipped[:, 2] - clipped[:, 0]) * (clipped[:, 3] - clipped[:, 1])) / area
+    mask = (outside == 0) & ((lost < (1 - alpha)).astype(int) == 1)
+    return clipped[mask, :], mask
+
+
+def _axis_spans(length, tile_size, step):
+    start = np.arange(0, length, step)
+    end = start + tile_size
+    keep = end <= length
+    start, end = np.append(start[keep], [max(0, length - tile_size)]), np.append(end[keep], [length])
+    return np.unique(np.stack([start, end], axis=1), axis=0)            # sorted, duplicates (last == a regular one) merged
+
+
+def tile_grid(width, height, tile_size, step):
+    """utils.py:343-372: [x0, y0, x1, y1] of every tile, rows first; the last tile of an axis is flush with the border."""
+    xs, ys = _axis_spans(width, tile_size, step), _axis_spans(height, tile_size, step)
+    return [[int(x[0]), int(y[0]), int(x[1]), int(y[1])] for y in ys for x in xs]
+
+
+class TileFeed:
+    """Iterator over training samples (see module docstring).  data: list of {filepath, width, height, bboxes:[{class,x1,
+    y1,x2,y2}]}; class_count: {class: number of boxes} (utils.get_data's third return value)."""
+
+    def __init__(self, data, C, class_count, load_image, train_mode=True, rng=None, resize=None):
+        self.data, self.C, self.load_image, self.train_mode = data, C, load_image, train_mode
+        self.rng = np.random if rng is None else rng
+        self.selector = SampleSelector(class_count)
+        self.resize = resize                      # (img, new_w, new_h) -> img; default: the device bicubic kernel
+        if train_mode:
+            on = [k for k in AUGMENT_SWITCHES if getattr(C, k, False)]
+            if on:
+                raise NotImplementedError("augmentation is not built (SURVEY.md 8f N4): switch off " + ", ".join(on))
+
+    def _image(self, img_data, random_type):
+        types = self.C.img_types
+        img_type = types[0]
+        if random_type:                           # utils.get_image (utils.py:111-122)
+            first = 0.5 if len(types) <= 3 else 0.3
+            probs = [first] + [(1.0 - first) / (len(types) - 1) for _ in range(len(types) - 1)]
+            img_type = self.rng.choice(types, 1, p=probs)[0]
+        return self.load_image(img_data, img_type)
+
+    def _sample(self, img, img_data):
+        C = self.C
+        width, height = img_data["width"], img_data["height"]
+        if img.shape[1] != width or img.shape[0] != height:
+            raise AssertionError("image size does not match its annotation")           # utils.py:437-438
+        new_w, new_h = get_new_img_size(width, height, C.img_size)
+        if (new_w, new_h) != (width, height):
+            if self.resize is not None:
+                img = self.resize(img, new_w, new_h)
+            else:
+                from .RADNet import resize_cubic
+                img = resize_cubic(img, new_w, new_h)
+        return dict(img=np.ascontiguousarray(img), bboxes=img_data["bboxes"], width=width, height=height,
+                    filepath=img_data.get("filepath"))
+
+    def __iter__(self):
+        C, sel = self.C, self.selector
+        balanced = self.train_mode and C.balanced_classes
+        while True:
+            if self.train_mode:
+                self.rng.shuffle(self.data)
+            for img_data in self.data:
+                if balanced and sel.skip_image_for_balanced_class(img_data):
+                    continue
+                tiles = tile_grid(img_data["width"], img_data["height"], C.tile_size, C.tile_overlap)
+                left = np.arange(0, len(tiles))
+                n_tiles = min(len(tiles), C.max_n_tiles_train if self.train_mode else C.max_n_tiles_val)
+                done = 0
+                while done < n_tiles and len(left) > 0:
+                    img = self._image(img_data, C.use_img_type)
+                    pick = self.rng.randint(0, len(left))
+                    tile = tiles[left[pick]]
+                    left = np.delete(left, pick)
+                    boxes = img_data["bboxes"]
+                    arr = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in boxes])
+                    arr, keep = clip_box(arr, tile, C.tile_bbox_clip_threshold)
+                    kept = [copy.deepcopy(boxes[i]) for i in range(keep.shape[0]) if keep[i] == 1]
+                    if not kept:
+                        continue
+                    for i, b in enumerate(kept):
+                        b["x1"], b["y1"] = int(arr[i, 0] - tile[0]), int(arr[i, 1] - tile[1])
+                        b["x2"], b["y2"] = int(math.ceil(arr[i, 2] - tile[0])), int(math.ceil(arr[i, 3] - tile[1]))
+                    crop = np.copy(img[tile[1]:tile[3], tile[0]:tile[2], :])
+                    tile_data = dict(img_data, bboxes=kept, width=crop.shape[1], height=crop.shape[0])
+                    if balanced and sel.skip_tile_for_balanced_class(tile_data):
+                        continue
+                    done += 1
+                    yield self._sample(crop, tile_data)
+                if C.include_full_img:
+                    if balanced and sel.skip_tile_for_balanced_class(img_data):
+                        continue
+                    img = self._image(img_data, C.use_img_type)
+                    yield self._sample(img, copy.deepcopy(img_data))
+            if not self.train_mode:
+                return
+
+
+def run_training(ts, feed, n_steps, lookahead=3, on_step=None):
+    """Drive a TrainStep from a sample iterator, one sample per batch, announcing `lookahead` batches ahead (the pipelined
+    step).  With lookahead > 0 the feed must draw from its own RandomState (see module docstring).  Returns the number of
+    steps run."""
+    it = iter(feed)
+    window = []
+    done = 0
+
+    def fill():
+        while len(window) < lookahead + 1:
+            try:
+                window.append([next(it)])
+            except StopIteration:
+                break
+
+    fill()
+    while window and done < n_steps:
+        batch = window.pop(0)
+        fill()
+        ts.step(batch, upcoming=window[:min(lookahead, n_steps - 1 - done)] if lookahead else None)
+        done += 1
+        if on_step is not None:
+            on_step(done, ts)
+    ts.flush()
+    return done

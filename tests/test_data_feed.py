@@ -1,0 +1,103 @@
+"""Host data feed (faster_rcnn/data_feed.py) against vectors produced by the reference's own
+get_tile_generator / SampleSelector / clip_box on a synthetic in-memory dataset (tools/gen_golden_feed.py):
+same tiles in the same order, same clipped boxes, same consumption of NumPy's global random stream.  The reference computes
+the anchor labels inside its generator (drawing from the same stream); here the step does that, so between two samples the
+test advances the stream with the oracle's calc_region_props restatement (itself pinned by tests/golden/calc_region_props)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from faster_rcnn import data_feed as F
+from faster_rcnn.config import Config
+from oracle import glue
+
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tile_feed.json")))
+CLASSES = ["boat", "human", "other", "animal", "circle", "wheel"]
+AUG = ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear", "use_brightness", "use_noise")
+
+
+def dataset(seed, sizes):                       # the generator tools/gen_golden_feed.py used
+    rs = np.random.RandomState(seed)
+    data, imgs = [], {}
+    for i, (w, h) in enumerate(sizes):
+        path = "data/img_%d.png" % i
+        boxes = []
+        for j in range(int(rs.randint(3, 9))):
+            bw, bh = int(rs.randint(30, 150)), int(rs.randint(30, 150))
+            x1, y1 = int(rs.randint(0, max(1, w - bw))), int(rs.randint(0, max(1, h - bh)))
+            boxes.append({"class": CLASSES[int(rs.randint(len(CLASSES)))], "x1": x1, "x2": x1 + bw, "y1": y1, "y2": y1 + bh})
+        data.append({"filepath": path, "width": w, "height": h, "bboxes": boxes})
+        imgs[path] = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    return data, imgs
+
+
+def test_clip_box_matches_reference():
+    for c in G["clip_box"]:
+        clipped, mask = F.clip_box(np.array(c["boxes"]), c["img_box"], c["alpha"])
+        assert [bool(m) for m in mask] == c["mask"]
+        assert np.array_equal(clipped, np.array(c["clipped"]).reshape(-1, 4))
+
+
+def test_sample_selector_matches_reference():
+    sel = F.SampleSelector(dict((k, v) for k, v in G["selector"]["counts"]))
+    for s in G["selector"]["seq"]:
+        img = {"bboxes": [{"class": c} for c in s["classes"]]}
+        res = sel.skip_tile_for_balanced_class(img) if s["tile"] else sel.skip_image_for_balanced_class(img)
+        assert bool(res) == s["skip"] and sel.curr_class == s["curr"]
+
+
+def test_tile_grid():
+    assert F.tile_grid(300, 300, 300, 150) == [[0, 0, 300, 300]]
+    g = F.tile_grid(900, 700, 300, 150)
+    assert g[0] == [0, 0, 300, 300] and g[-1] == [600, 400, 900, 700] and len(g) == 5 * 4
+    assert [t[0] for t in g[:5]] == [0, 150, 300, 450, 600] and sorted({t[1] for t in g}) == [0, 150, 300, 400]
+    assert F.tile_grid(200, 250, 300, 150) == [[0, 0, 200, 250]]          # image smaller than a tile: one tile, whole image
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_tile_feed_matches_reference_generator(case):
+    C = Config()
+    C.img_size, C.tile_size, C.tile_overlap = 300, 300, 150
+    C.max_n_tiles_train, C.max_n_tiles_val = 2, 3
+    C.balanced_classes, C.include_full_img, C.use_img_type = case["balanced"], False, False
+    for k in AUG:
+        setattr(C, k, False)
+    data, imgs = dataset(case["data_seed"], [tuple(s) for s in case["sizes"]])
+    class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in CLASSES}
+    np.random.seed(case["seed"])
+    feed = iter(F.TileFeed(data, C, class_count, lambda d, t: imgs[d["filepath"]], train_mode=case["train"]))
+    got = 0
+    for ref in case["yields"]:
+        s = next(feed)
+        assert (s["filepath"], s["width"], s["height"]) == (ref["filepath"], ref["width"], ref["height"])
+        assert [{k: b[k] for k in ("class", "x1", "y1", "x2", "y2")} for b in s["bboxes"]] == ref["bboxes"]
+        assert int(s["img"].astype(np.int64).sum()) == ref["img_sum"] and s["img"].dtype == np.uint8
+        # the reference's generator now labels the anchors, drawing from the same stream (utils.py:451)
+        boxes = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in s["bboxes"]], dtype=np.float64)
+        is_bg = np.array([b["class"] == "bg" for b in s["bboxes"]])
+        rw, rh = glue.new_img_size(s["width"], s["height"], C.img_size)
+        n_pos = glue.anchor_targets(C, boxes, is_bg, s["width"], s["height"], rw, rh, lambda w, h: (glue.resnet50_feat_len(w), glue.resnet50_feat_len(h)))[3]
+        assert int(n_pos) == ref["n_pos"]
+        got += 1
+    if not case["train"]:
+        with pytest.raises(StopIteration):          # one pass in validation mode (the reference ends it with an exception)
+            next(feed)
+    assert np.random.randint(0, 2 ** 31 - 1) == case["rng_after"]
+
+
+def test_augmentation_switches_are_refused_and_private_rng():
+    C = Config()
+    with pytest.raises(NotImplementedError):
+        F.TileFeed([], C, {"boat": 1}, None, train_mode=True)          # the default Config has the augmentations on
+    for k in AUG:
+        setattr(C, k, False)
+    C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, False
+    data, imgs = dataset(3, [(640, 480), (300, 300)])
+    np.random.seed(1)
+    probe = np.random.RandomState(1).randint(0, 2 ** 31 - 1)
+    feed = iter(F.TileFeed(data, C, {c: 1 for c in CLASSES}, lambda d, t: imgs[d["filepath"]], rng=np.random.RandomState(9)))
+    for _ in range(5):
+        next(feed)
+    assert np.random.randint(0, 2 ** 31 - 1) == probe                   # the global stream was not touched

@@ -321,3 +321,55 @@ def test_changed_announcement_is_refused():
     ts.step(b1)                                  # the announced batch is still accepted
     ts.flush()
     assert ts.losses()["n_head"] == 1
+
+
+def test_run_training_from_tile_feed():
+    """faster_rcnn.data_feed: TileFeed -> TrainStep through run_training, pulled three samples ahead (pipelined step) and one
+    by one (one lane): same samples (the feed draws from its own RandomState), same training result."""
+    from faster_rcnn import data_feed as F
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, True
+    for k in F.AUGMENT_SWITCHES:
+        setattr(C, k, False)
+    rs = np.random.RandomState(5)
+    classes = [k for k in C.class_mapping if k != "bg"]
+    data, imgs = [], {}
+    for i, (w, h) in enumerate([(640, 480), (300, 300), (500, 700)]):
+        boxes = []
+        for j in range(6):
+            bw, bh = int(rs.randint(40, 140)), int(rs.randint(40, 140))
+            x1, y1 = int(rs.randint(0, w - bw)), int(rs.randint(0, h - bh))
+            boxes.append({"class": classes[j % len(classes)], "x1": x1, "x2": x1 + bw, "y1": y1, "y2": y1 + bh})
+        data.append({"filepath": "img%d" % i, "width": w, "height": h, "bboxes": boxes})
+        imgs["img%d" % i] = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in classes}
+    P = dense.init_params(seed=3)
+    out = []
+    tune = None
+    for lookahead in (0, 3):
+        eng = FasterRCNNEngine(C)
+        if tune is not None:
+            eng.load_tuning(tune)                     # same launch shapes -> same summation order
+        eng.set_weights(P)
+        np.random.seed(64)
+        ts = TrainStep(eng)
+        feed = F.TileFeed([dict(d) for d in data], C, class_count, lambda d, t: imgs[d["filepath"]], rng=np.random.RandomState(7))
+        seen = []
+        n = F.run_training(ts, feed, 6, lookahead=lookahead, on_step=lambda k, t: seen.append(t.last[0]))
+        assert n == 6 and len(seen) == 6
+        out.append((eng.get_weights(), np.random.randint(0, 2 ** 31 - 1), ts.skipped_head_steps))
+        if tune is None:
+            import tempfile
+            tune = tempfile.mktemp(suffix=".txt")
+            eng.save_tuning(tune)
+    (w0, r0, s0), (w1, r1, s1) = out
+    assert r0 == r1 and s0 == s1
+    # wgrad sums its K slices with fp32 atomics (order varies from run to run) and Adam turns a last-bit difference of a tiny
+    # gradient into a visible fraction of lr = 5e-5: almost every weight agrees to the last bits, none moves by more than lr / 10
+    for name in ("rpn_conv1", "res5a_branch2a", "dense_class_7"):
+        d = np.abs(w0[name]["kernel"] - w1[name]["kernel"])
+        assert d.max() < 5e-6 and np.mean(d < 3e-7) > 0.999, (name, float(d.max()), float(np.mean(d < 3e-7)))
