@@ -80,3 +80,50 @@ def mean_average_precision(all_dets, all_gt, threshold=0.5):
         acc[key] = calc_class_ap(T[key], P[key])[0]
     acc["mAP"] = np.mean(np.array([acc[k] for k in sorted(T.keys())]))
     return acc
+
+
+def augment_geometric_loops(boxes, img, flips, angle):
+    """augmentation.py:85-159 restated with explicit pixel loops (test infrastructure): flips = (horizontal, vertical)
+    booleans, angle in (None, 90, 180, 270), applied in the reference's order.  Returns (boxes, img)."""
+    boxes = [dict(b) for b in boxes]
+    if flips[0]:
+        rows, cols = img.shape[:2]
+        out = np.empty_like(img)
+        for x in range(cols):
+            out[:, x] = img[:, cols - 1 - x]                    # cv2.flip(img, 1)
+        img = out
+        for b in boxes:
+            x1, x2 = b["x1"], b["x2"]
+            b["x2"], b["x1"] = cols - x1, cols - x2
+    if flips[1]:
+        rows, cols = img.shape[:2]
+        out = np.empty_like(img)
+        for y in range(rows):
+            out[y] = img[rows - 1 - y]                          # cv2.flip(img, 0)
+        img = out
+        for b in boxes:
+            y1, y2 = b["y1"], b["y2"]
+            b["y2"], b["y1"] = rows - y1, rows - y2
+    if angle is not None:
+        rows, cols = img.shape[:2]
+        if angle == 180:
+            out = np.empty_like(img)
+            for y in range(rows):
+                for x in range(cols):
+                    out[y, x] = img[rows - 1 - y, cols - 1 - x]  # cv2.flip(img, -1)
+        else:
+            out = np.empty((cols, rows) + img.shape[2:], img.dtype)
+            for y in range(cols):
+                for x in range(rows):
+                    # transpose, then flip rows (270) or columns (90)
+                    out[y, x] = img[x, cols - 1 - y] if angle == 270 else img[rows - 1 - x, y]
+        img = out
+        for b in boxes:
+            x1, x2, y1, y2 = b["x1"], b["x2"], b["y1"], b["y2"]
+            if angle == 270:
+                b["x1"], b["x2"], b["y1"], b["y2"] = y1, y2, cols - x2, cols - x1
+            elif angle == 180:
+                b["x2"], b["x1"], b["y2"], b["y1"] = cols - x1, cols - x2, rows - y1, rows - y2
+            else:
+                b["x1"], b["x2"], b["y1"], b["y2"] = rows - y2, rows - y1, x1, x2
+    return boxes, img

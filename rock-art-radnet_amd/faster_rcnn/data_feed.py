@@ -9,8 +9,11 @@ Same control flow and the same draws from the random stream as the reference, in
   tile (drop those left with less than C.tile_bbox_clip_threshold of their area) -> tile coordinates (int / ceil) ->
   skip empty tiles and tiles without the class whose turn it is -> resize to get_new_img_size (bicubic, on the device);
   then the full image when C.include_full_img.
-Augmentation (augmentation.py:85-533) is not built: in train mode every C.use_* augmentation switch must
-be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
+Augmentation (augmentation.py:85-533): the three exact geometric ones are built -- horizontal / vertical
+flip, rotation by 90 / 180 / 270 degrees (augmentation.py:85-159; array reversals and transposes, so no interpolation is
+involved), with the reference's draws (np.random.random() < 0.5 per enabled switch, in its order; np.random.choice over
+the angle).  Arbitrary rotation, shear, brightness and noise need OpenCV / scikit-image semantics that cannot be pinned
+here: in train mode those switches must be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
 HWC`): OpenCV, which the reference decodes with, is not part of this build.
 
 rng: None = NumPy's global stream, i.e. exactly the reference's interleaving with the step's own draws when samples are
@@ -27,6 +30,42 @@ from .utils import get_new_img_size
 
 AUGMENT_SWITCHES = ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear",
                     "use_brightness", "use_noise")          # augmentation.py:495-518
+EXACT_AUGMENTATIONS = AUGMENT_SWITCHES[:3]
+
+
+def augment_geometric(img_data, img, C, rng=np.random):
+    """augmentation.augment (augmentation.py:481-533) restricted to its exact geometric branches; img_data['bboxes'] is
+    edited in place like the reference edits its deep copy.  Returns (img_data, img) with width / height updated."""
+    boxes = img_data["bboxes"]
+    if C.use_horizontal_flips and rng.random() < 0.5:           # augmentation.py:85-99: x -> cols - x, ends swapped
+        cols = img.shape[1]
+        img = img[:, ::-1]
+        for b in boxes:
+            b["x1"], b["x2"] = cols - b["x2"], cols - b["x1"]
+    if C.use_vertical_flips and rng.random() < 0.5:             # augmentation.py:101-115
+        rows = img.shape[0]
+        img = img[::-1]
+        for b in boxes:
+            b["y1"], b["y2"] = rows - b["y2"], rows - b["y1"]
+    if C.use_90_rotations and rng.random() < 0.5:               # augmentation.py:117-159
+        rows, cols = img.shape[:2]
+        angle = rng.choice([90, 180, 270], 1)[0]
+        if angle == 270:
+            img = np.transpose(img, (1, 0, 2))[::-1]
+        elif angle == 180:
+            img = img[::-1, ::-1]
+        else:
+            img = np.transpose(img, (1, 0, 2))[:, ::-1]
+        for b in boxes:
+            x1, x2, y1, y2 = b["x1"], b["x2"], b["y1"], b["y2"]
+            if angle == 270:
+                b["x1"], b["x2"], b["y1"], b["y2"] = y1, y2, cols - x2, cols - x1
+            elif angle == 180:
+                b["x1"], b["x2"], b["y1"], b["y2"] = cols - x2, cols - x1, rows - y2, rows - y1
+            else:
+                b["x1"], b["x2"], b["y1"], b["y2"] = rows - y2, rows - y1, x1, x2
+    img_data["width"], img_data["height"] = img.shape[1], img.shape[0]
+    return img_data, np.ascontiguousarray(img)
 
 
 class SampleSelector:
@@ -89,9 +128,9 @@ class TileFeed:
         self.selector = SampleSelector(class_count)
         self.resize = resize                      # (img, new_w, new_h) -> img; default: the device bicubic kernel
         if train_mode:
-            on = [k for k in AUGMENT_SWITCHES if getattr(C, k, False)]
+            on = [k for k in AUGMENT_SWITCHES if getattr(C, k, False) and k not in EXACT_AUGMENTATIONS]
             if on:
-                raise NotImplementedError("augmentation is not built (SURVEY.md 8f N4): switch off " + ", ".join(on))
+                raise NotImplementedError("only the exact geometric augmentations are built (SURVEY.md 8f N4): switch off " + ", ".join(on))
 
     def _image(self, img_data, random_type):
         types = self.C.img_types
@@ -148,13 +187,18 @@ class TileFeed:
                     tile_data = dict(img_data, bboxes=kept, width=crop.shape[1], height=crop.shape[0])
                     if balanced and sel.skip_tile_for_balanced_class(tile_data):
                         continue
+                    if self.train_mode:
+                        tile_data, crop = augment_geometric(tile_data, crop, C, self.rng)
                     done += 1
                     yield self._sample(crop, tile_data)
                 if C.include_full_img:
                     if balanced and sel.skip_tile_for_balanced_class(img_data):
                         continue
                     img = self._image(img_data, C.use_img_type)
-                    yield self._sample(img, copy.deepcopy(img_data))
+                    full = copy.deepcopy(img_data)
+                    if self.train_mode:
+                        full, img = augment_geometric(full, img, C, self.rng)
+                    yield self._sample(img, full)
             if not self.train_mode:
                 return
 

@@ -101,3 +101,40 @@ def test_augmentation_switches_are_refused_and_private_rng():
     for _ in range(5):
         next(feed)
     assert np.random.randint(0, 2 ** 31 - 1) == probe                   # the global stream was not touched
+
+
+def test_geometric_augmentations_vs_loop_restatement():
+    """Flips / 90-degree rotations (augmentation.py:85-159): array reversals and transposes, no interpolation.  Parity
+    unpinned against OpenCV's cv2.flip itself (absent); checked against explicit pixel loops, for every draw outcome, and
+    that a box keeps covering the same pixels."""
+    from oracle.evaluate import augment_geometric_loops
+
+    class FixedRng:                                   # replays chosen outcomes in the order the reference draws them
+        def __init__(self, coins, angle):
+            self.coins, self.angle = list(coins), angle
+        def random(self):
+            return self.coins.pop(0)
+        def choice(self, a, n):
+            return np.array([self.angle])
+
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    boxes = [{"class": "boat", "x1": 5, "y1": 7, "x2": 20, "y2": 30}, {"class": "human", "x1": 0, "y1": 0, "x2": 53, "y2": 37}]
+    C = Config()
+    C.use_horizontal_flips = C.use_vertical_flips = C.use_90_rotations = True
+    for hf in (False, True):
+        for vf in (False, True):
+            for angle in (None, 90, 180, 270):
+                coins = [0.1 if hf else 0.9, 0.1 if vf else 0.9, 0.1 if angle else 0.9]
+                data = {"bboxes": [dict(b) for b in boxes], "width": 53, "height": 37}
+                d, out = F.augment_geometric(data, img, C, FixedRng(coins, angle))
+                rb, rimg = augment_geometric_loops(boxes, img, (hf, vf), angle)
+                assert np.array_equal(out, rimg) and d["bboxes"] == rb
+                assert (d["width"], d["height"]) == (out.shape[1], out.shape[0])
+                b0, o0 = d["bboxes"][0], boxes[0]                   # the box still frames the same pixels
+                assert sorted(out[b0["y1"]:b0["y2"], b0["x1"]:b0["x2"]].ravel()) == sorted(img[o0["y1"]:o0["y2"], o0["x1"]:o0["x2"]].ravel())
+    # a switched-off augmentation draws nothing
+    C.use_vertical_flips = False
+    rng = FixedRng([0.9, 0.9], 90)
+    F.augment_geometric({"bboxes": [], "width": 53, "height": 37}, img, C, rng)
+    assert rng.coins == []
