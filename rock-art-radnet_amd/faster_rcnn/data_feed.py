@@ -68,6 +68,34 @@ def augment_geometric(img_data, img, C, rng=np.random):
     return img_data, np.ascontiguousarray(img)
 
 
+def get_data(annot_path, data_path, img_types, load_image):
+    """utils.get_data (utils.py:134-220): annotation CSV (columns img_path, label, xmin, ymin, xmax, ymax; one box per row)
+    -> (data, class_count, class_mapping).  data: one {filepath, width, height, depth, bboxes} per image, in order of first
+    appearance, filepath = data_path + '/' + img_path; an image is decoded once (load_image(img_data, img_types[0]), the
+    caller's decoder) for its size, as the reference does; classes are numbered in order of first appearance and 'bg' is
+    appended when no row carries it."""
+    import csv
+    images, class_count, class_mapping = {}, {}, {}
+    with open(annot_path, newline="") as f:
+        for row in csv.DictReader(f):
+            name, cls = row["img_path"], row["label"]
+            class_count[cls] = class_count.get(cls, 0) + 1
+            if cls not in class_mapping:
+                class_mapping[cls] = len(class_mapping)
+            if name not in images:
+                entry = {"filepath": data_path + "/" + name}
+                img = load_image(entry, img_types[0])
+                entry.update(width=img.shape[1], height=img.shape[0], depth=img.shape[2], bboxes=[])
+                images[name] = entry
+            # int() of the parsed number, like int(df.loc[i, 'xmin']): fractional coordinates truncate towards zero
+            images[name]["bboxes"].append({"class": cls, "x1": int(float(row["xmin"])), "y1": int(float(row["ymin"])),
+                                           "x2": int(float(row["xmax"])), "y2": int(float(row["ymax"]))})
+    if "bg" not in class_count:
+        class_count["bg"] = 0
+        class_mapping["bg"] = len(class_mapping)
+    return list(images.values()), class_count, class_mapping
+
+
 class SampleSelector:
     """utils.py:19-59: cycle through the classes that occur; an image is skipped unless it holds the class whose turn it
     is, a tile likewise -- and a tile that does hold it advances the turn."""

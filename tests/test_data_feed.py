@@ -138,3 +138,13 @@ def test_geometric_augmentations_vs_loop_restatement():
     rng = FixedRng([0.9, 0.9], 90)
     F.augment_geometric({"bboxes": [], "width": 53, "height": 37}, img, C, rng)
     assert rng.coins == []
+
+
+def test_get_data_matches_reference(tmp_path):
+    g = G["get_data"]
+    p = tmp_path / "annot.csv"
+    p.write_text("\n".join(g["csv"]) + "\n")
+    sizes = g["sizes"]
+    data, cc, cm = F.get_data(str(p), "D", ["t0", "t1"], lambda d, t: np.zeros((sizes[d["filepath"]][1], sizes[d["filepath"]][0], 3), np.uint8))
+    assert data == g["data"]
+    assert [[k, v] for k, v in cc.items()] == g["class_count"] and [[k, v] for k, v in cm.items()] == g["class_mapping"]

@@ -91,6 +91,23 @@ def main():
         out["cases"].append({"name": name, "seed": 100 + seed, "train": train, "balanced": balanced, "sizes": sizes, "data_seed": seed,
                              "yields": yields, "rng_after": int(np.random.randint(0, 2 ** 31 - 1))})
         print(name, len(yields), "yields")
+    # ---- get_data ---------------------------------------------------------------------------------------------------
+    import tempfile
+    rs = np.random.RandomState(31)
+    rows, sizes = ["img_path,label,xmin,ymin,xmax,ymax"], {}
+    names = ["a/p1.png", "b/p2.png", "a/p3.png"]
+    for i in range(17):
+        nm = names[int(rs.randint(3))]
+        sizes.setdefault("D/" + nm, (int(rs.randint(200, 900)), int(rs.randint(200, 900))))
+        x1, y1 = rs.uniform(0, 150, 2)
+        rows.append("%s,%s,%.2f,%.2f,%.2f,%.2f" % (nm, classes[int(rs.randint(1, 5))], x1, y1, x1 + rs.uniform(5, 90), y1 + rs.uniform(5, 90)))
+    tmp = tempfile.mkdtemp()
+    csv_path = os.path.join(tmp, "annot.csv")
+    open(csv_path, "w").write("\n".join(rows) + "\n")
+    rutils.get_image = lambda path, types, random_type=False: np.zeros((sizes[path][1], sizes[path][0], 3), np.uint8)
+    data, cc, cm = rutils.get_data(csv_path, "D", ["t0", "t1"])
+    out["get_data"] = {"csv": rows, "sizes": {k: list(v) for k, v in sizes.items()}, "data": data,
+                       "class_count": [[k, int(v)] for k, v in cc.items()], "class_mapping": [[k, int(v)] for k, v in cm.items()]}
     with open(os.path.join(G.OUT, "tile_feed.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
 
