@@ -7,7 +7,7 @@ train (fwd+loss+bwd+Adam#2) -- nothing skipped (a step whose head phase is skipp
 Inputs (uint8 panels, GT boxes) are resident before the timed region; the panel is uploaded once per step
 from pinned host memory exactly as the reference feeds its model (the PCIe copy is inside the step).
 
-  python bench.py --gpus 1 --steps 100 --warmup 20
+  python bench.py --gpus 1 --steps 300 --warmup 30
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -79,8 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: ~0.4 s of timed work -- a 20-step (70 ms) window is short enough for one host hiccup or a clock ramp
     # after the sync-heavy tuning phase to move the figure by several per cent (tools/variance_probe.py)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--per-gpu-batch", type=int, default=1)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
