@@ -147,7 +147,7 @@ def main():
             skipped_head_steps = property(lambda self: _ts.skipped_head_steps)
 
             def step(self, batch, next_batch=None, after_next=None, upcoming=None):
-                return _ts.step(batch)
+                return _ts.step(batch, upcoming=upcoming)
 
             def flush(self):
                 pass

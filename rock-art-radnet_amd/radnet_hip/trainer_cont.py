@@ -21,6 +21,8 @@ class ContTrainStep:
 
     def __init__(self, eng, dist_group=None, world_size=1):
         self.eng = eng
+        self._pre = None                 # next batch's labelling kernels, upload and frozen stem, enqueued on the side lane
+        self._slot = 0
         self.world = world_size
         self.group = dist_group
         self.skipped_head_steps = 0
@@ -39,20 +41,43 @@ class ContTrainStep:
             s["_gt_dev"] = self.eng.upload_gt(boxes, isbg, cls)
         return s["_gt_dev"]
 
-    def step(self, batch):
+    def _launch_stem(self, batch, slot):
+        """What does not depend on any trainable weight: labelling kernels, upload, conv1 .. stage 2 (frozen)."""
+        eng = self.eng
+        nloc = len(batch)
+        tp, plans = [], []
+        for i, s in enumerate(batch):
+            H, W = s["img"].shape[:2]
+            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=slot * nloc + i))
+        for i, s in enumerate(batch):
+            bp = eng.upload_image(s["img"], slot=slot * nloc + i)
+            eng.stem_forward(bp)                       # frozen: once per image
+            plans.append(bp)
+        return dict(batch=batch, tp=tp, plans=plans)
+
+    def step(self, batch, upcoming=None):
+        """upcoming (optional): the next call's batch -- its labelling kernels, upload and frozen stem run on the engine's
+        side lane beside this step (everything else of cont_train.py's step depends on weights both optimizers move)."""
         eng = self.eng
         C = eng.C
         nloc = len(batch)
         ntot = nloc * self.world
-        tp, plans, rps = [], [], []
-        for i, s in enumerate(batch):
-            H, W = s["img"].shape[:2]
-            tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=i))
-        for i, s in enumerate(batch):
-            bp = eng.upload_image(s["img"], slot=i)
-            eng.stem_forward(bp)                       # frozen: once per image
+        st = self._pre if self._pre is not None and self._pre["batch"] is batch else None
+        self._pre = None
+        if st is None:
+            st = self._launch_stem(batch, self._slot)
+        else:
+            eng.after(st["done"])
+        self._slot ^= 1
+        if upcoming and hasattr(eng, "lane") and not eng.ctx.timing_on:
+            ev = eng.mark()                            # the other buffer set was last read by the previous step (main lane)
+            with eng.lane("side"):
+                eng.after(ev)
+                self._pre = self._launch_stem(upcoming[0], self._slot)
+                self._pre["done"] = eng.mark()
+        tp, plans, rps = st["tp"], st["plans"], []
+        for bp in plans:
             eng.s34_forward(bp)
-            plans.append(bp)
             rps.append(eng.rpn_forward(bp))
         # ---- RPN model: loss, gradients of the RPN convs and (via dL/dF) of stages 3-4, Adam #1 over both
         for i in range(nloc):
