@@ -35,6 +35,8 @@ def main():
         if force:
             fa, fb, fs = (int(v) for v in force.split(","))
             c.check(c.lib.radnet_force_config(c.h, fa, fb, fs), "force")
+            if os.environ.get("PROBE_FORCE_WAVES"):
+                c.check(c.lib.radnet_force_waves(c.h, int(os.environ["PROBE_FORCE_WAVES"])), "force waves")
         ctxs.append(c)
     lib = ctxs[0].lib
     for name, (nb, h, w), cin, cout, k in CASES:
