@@ -1,5 +1,5 @@
 set -e
-TAG=${TAG:-v10}
+TAG=${TAG:-v11}
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=gpurun_out/$TAG/tune.txt
