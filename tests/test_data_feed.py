@@ -148,3 +148,27 @@ def test_get_data_matches_reference(tmp_path):
     data, cc, cm = F.get_data(str(p), "D", ["t0", "t1"], lambda d, t: np.zeros((sizes[d["filepath"]][1], sizes[d["filepath"]][0], 3), np.uint8))
     assert data == g["data"]
     assert [[k, v] for k, v in cc.items()] == g["class_count"] and [[k, v] for k, v in cm.items()] == g["class_mapping"]
+
+
+def test_run_training_announces_the_right_batches():
+    """run_training pulls samples `lookahead` ahead of the step and announces exactly the batches the next calls bring, in
+    order; it stops announcing when the run is about to end and flushes once."""
+
+    class Recorder:
+        def __init__(self):
+            self.calls, self.flushed = [], 0
+        def step(self, batch, upcoming=None):
+            self.calls.append((batch[0]["id"], [b[0]["id"] for b in (upcoming or [])]))
+        def flush(self):
+            self.flushed += 1
+
+    feed = ({"id": i} for i in range(100))
+    ts = Recorder()
+    assert F.run_training(ts, feed, 6, lookahead=3) == 6 and ts.flushed == 1
+    assert ts.calls == [(0, [1, 2, 3]), (1, [2, 3, 4]), (2, [3, 4, 5]), (3, [4, 5]), (4, [5]), (5, [])]
+    ts = Recorder()
+    assert F.run_training(ts, iter([{"id": 0}, {"id": 1}]), 10, lookahead=3) == 2          # feed shorter than the run
+    assert ts.calls == [(0, [1]), (1, [])]
+    ts = Recorder()
+    F.run_training(ts, ({"id": i} for i in range(9)), 3, lookahead=0)
+    assert ts.calls == [(0, []), (1, []), (2, [])]
