@@ -48,7 +48,7 @@ class RADNet():
         """Back to source-image pixels: floor-division by the resize ratio, then round (RADNet.py:44-51)."""
         return tuple(int(round(v // ratio)) for v in (x1, y1, x2, y2))
 
-    def format_img_size(self, img, keep_on_device=False):
+    def format_img_size(self, img, keep_on_device=False, ctx=None):
         """Short side -> C.img_size, long side truncated (RADNet.py:53-74); bicubic resize on the device.
         keep_on_device: return the resized uint8 image as a device tensor (the device-resident tile path)."""
         side = float(self.C.img_size)
@@ -60,7 +60,7 @@ class RADNet():
             ratio = side / height
             new_w, new_h = int(ratio * width), int(side)
         if keep_on_device:
-            return resize_cubic(img, new_w, new_h, to_host=False), ratio
+            return resize_cubic(img, new_w, new_h, to_host=False, ctx=ctx), ratio
         if (new_h, new_w) != (height, width):
             img = resize_cubic(img, new_w, new_h)
         return img, ratio
@@ -78,11 +78,21 @@ class RADNet():
         """RADNet.py:104-154.  R (n,4) xywh in feature-map units.  The RoIs go through the detector n_rois at a
         time, the last chunk padded with copies of its first RoI; confident non-background RoIs are decoded with
         their class's deltas and scaled to resized-image pixels."""
-        C = self.C
-        k = C.n_rois
-        stride = C.rpn_stride
-        std = C.classifier_regr_std
-        bboxes, probs = {}, {}
+        chunks = self._spp_chunks(R)
+        # The reference's Keras detector is built for exactly n_rois RoIs, hence its 15 calls per tile.  The HIP
+        # detector takes any count (every RoI is independent under TimeDistributed), so all chunks -- padding rows
+        # included, they are decoded too -- go through ONE head pass: GEMM M = 14 700 instead of 15 x 980 (SURVEY 8d).
+        k = self.C.n_rois
+        if chunks and getattr(self.model_detector, "accepts_any_roi_count", False):
+            pc, pr = self.model_detector.predict([feature_map, np.concatenate(chunks, axis=1)])
+            outs = [(pc[:, i * k:(i + 1) * k], pr[:, i * k:(i + 1) * k]) for i in range(len(chunks))]
+        else:
+            outs = [tuple(self.model_detector.predict([feature_map, ROIs])) for ROIs in chunks]
+        return self._spp_decode(chunks, outs)
+
+    def _spp_chunks(self, R):
+        """RoIs n_rois at a time, the last chunk padded with copies of its first RoI (RADNet.py:110-122)."""
+        k = self.C.n_rois
         chunks = []
         for start in range(0, R.shape[0], k):
             chunk = R[start:start + k, :]
@@ -92,17 +102,15 @@ class RADNet():
                 padded[chunk.shape[0]:] = chunk[0]
                 chunk = padded
             chunks.append(np.expand_dims(chunk, axis=0))
-        # The reference's Keras detector is built for exactly n_rois RoIs, hence its 15 calls per tile.  The HIP
-        # detector takes any count (every RoI is independent under TimeDistributed), so all chunks -- padding rows
-        # included, they are decoded too -- go through ONE head pass: GEMM M = 14 700 instead of 15 x 980.
-        if chunks and getattr(self.model_detector, "accepts_any_roi_count", False):
-            allr = np.concatenate(chunks, axis=1)
-            pc, pr = self.model_detector.predict([feature_map, allr])
-            outs = [(pc[:, i * k:(i + 1) * k], pr[:, i * k:(i + 1) * k]) for i in range(len(chunks))]
-        else:
-            outs = None
-        for ci, ROIs in enumerate(chunks):
-            P_cls, P_regr = outs[ci] if outs is not None else self.model_detector.predict([feature_map, ROIs])
+        return chunks
+
+    def _spp_decode(self, chunks, outs):
+        """Confident non-background RoIs decoded with their class's deltas, in resized-image pixels (RADNet.py:124-154)."""
+        C = self.C
+        stride = C.rpn_stride
+        std = C.classifier_regr_std
+        bboxes, probs = {}, {}
+        for ROIs, (P_cls, P_regr) in zip(chunks, outs):
             for ii in range(P_cls.shape[1]):
                 scores = P_cls[0, ii, :]
                 best = int(np.argmax(scores))
@@ -175,6 +183,56 @@ class RADNet():
             out[key] = (real, [npr[j] for j in range(nb.shape[0])])
         return out
 
+    def _finish_detect(self, R, F, ratio):
+        R[:, 2] -= R[:, 0]
+        R[:, 3] -= R[:, 1]
+        bboxes, probs = self.apply_spatial_pyramid_pooling(R, F)
+        out = {}
+        for key in bboxes:
+            nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
+            real = [self.get_real_coordinates(ratio, *nb[j, :]) for j in range(nb.shape[0])]
+            out[key] = (real, [npr[j] for j in range(nb.shape[0])])
+        return out
+
+    def _detect_all(self, tiles):
+        """_detect over a list of tiles, in order.  With the engine-backed models two tiles are in flight: while the
+        classifier works on tile j (main lane), tile j+1 is uploaded, resized and run through the base network, the RPN and
+        the proposal kernels on the engine's side lane, in the other buffer set.  Same kernels, same results as _detect."""
+        eng = getattr(getattr(self.model_rpn, "_s", None), "eng", None)
+        if not (self.device_resident and hasattr(self.model_rpn, "propose_launch") and eng is not None and hasattr(eng, "lane") and len(tiles) > 1):
+            return [self._detect(t) for t in tiles]
+
+        def launch(j, head_done):
+            with eng.lane("side"):
+                eng.after(head_done)                     # the classifier pass that last read this buffer set
+                img_dev, ratio = self.format_img_size(tiles[j], keep_on_device=True, ctx=eng.ctx)
+                h = self.model_rpn.propose_launch(img_dev, overlap_thresh=0.7, slot=j % 2)
+                return h, ratio, eng.mark()
+
+        k = self.C.n_rois
+        out, done = [], [None, None]                     # per buffer set: event after the classifier pass that read it
+        nxt = launch(0, None)
+        for j in range(len(tiles)):
+            (h, ratio, ready), nxt = nxt, None
+            eng.after(ready)
+            R, F = self.model_rpn.propose_finish(h)
+            R[:, 2] -= R[:, 0]
+            R[:, 3] -= R[:, 1]
+            chunks = self._spp_chunks(R)
+            hp = self.model_detector.predict_launch([F, np.concatenate(chunks, axis=1)])      # enqueued, not waited for
+            done[j % 2] = eng.mark()
+            if j + 1 < len(tiles):                       # the next tile's upload .. proposals run beside this classifier pass
+                nxt = launch(j + 1, done[(j + 1) % 2])
+            pc, pr = self.model_detector.predict_finish(hp)
+            bboxes, probs = self._spp_decode(chunks, [(pc[:, i * k:(i + 1) * k], pr[:, i * k:(i + 1) * k]) for i in range(len(chunks))])
+            det = {}
+            for key in bboxes:
+                nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
+                real = [self.get_real_coordinates(ratio, *nb[i, :]) for i in range(nb.shape[0])]
+                det[key] = (real, [npr[i] for i in range(nb.shape[0])])
+            out.append(det)
+        return out
+
     def predict(self, images):
         """RADNet.py:502-718: tile -> RPN -> NMS -> RoI crop-resize -> classifier -> per-class NMS, box-averaging
         merge per image, then NMS 0.4 across images."""
@@ -191,11 +249,13 @@ class RADNet():
 
             if C.max_n_tiles_train > 0:                 # the reference gates tiling on this training knob (RADNet.py:511)
                 h, w = img.shape[:2]
-                for (ty0, ty1) in _spans(h, C.tile_size, C.tile_overlap):
-                    for (tx0, tx1) in _spans(w, C.tile_size, C.tile_overlap):
-                        collect(self._detect(np.copy(img[ty0:ty1, tx0:tx1, :])), tx0, ty0)
-            if C.include_full_img:
-                collect(self._detect(img), 0, 0)
+                spans = [(tx0, ty0, tx1, ty1) for (ty0, ty1) in _spans(h, C.tile_size, C.tile_overlap) for (tx0, tx1) in _spans(w, C.tile_size, C.tile_overlap)]
+            else:
+                spans = []
+            work = [np.copy(img[ty0:ty1, tx0:tx1, :]) for (tx0, ty0, tx1, ty1) in spans] + ([img] if C.include_full_img else [])
+            offs = [(tx0, ty0) for (tx0, ty0, tx1, ty1) in spans] + ([(0, 0)] if C.include_full_img else [])
+            for det, (ox, oy) in zip(self._detect_all(work), offs):
+                collect(det, ox, oy)
             for key in boxes_img:
                 nb, npr = self.final_nms(np.array(boxes_img[key]), np.array(probs_img[key]), obj_avg_threshold=0.2,
                                          obj_confidence_threshold=0.8, n_obj_avg=5)
@@ -222,12 +282,12 @@ class RADNet():
         return self.predict([get_image(img_path, [t], random_type=False) for t in types])
 
 
-def resize_cubic(img, new_w, new_h, to_host=True):
+def resize_cubic(img, new_w, new_h, to_host=True, ctx=None):
     """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_CUBIC) on the device (uint8 HWC).  to_host=False: the
     result stays a device tensor (an image already at the target size is just uploaded)."""
     import torch
     from radnet_hip import runtime as rt
-    ctx = rt.default_context()
+    ctx = rt.default_context() if ctx is None else ctx          # a lane's context: the kernel goes to that lane's stream
     src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
     if not to_host and (new_h, new_w) == tuple(img.shape[:2]):
         return src

@@ -48,12 +48,12 @@ class _Shared:
             self._x_key, self._bp, self._f_host = key, bp, None
         return self._bp
 
-    def base_from_u8(self, img_dev):
+    def base_from_u8(self, img_dev, slot=0):
         """Base features for a uint8 BGR HWC image that is ALREADY on the device at network size (RADNet's device-resident
-        tile path): preprocess kernel + base forward, nothing crosses PCIe."""
+        tile path): preprocess kernel + base forward, nothing crosses PCIe.  slot: buffer set (two tiles in flight)."""
         eng = self.eng
         H, W = int(img_dev.shape[0]), int(img_dev.shape[1])
-        bp = eng._plan_base(1, H, W, 0)
+        bp = eng._plan_base(1, H, W, slot)
         eng.ctx.call("radnet_preprocess_bgr", img_dev, H, W, 4, bp["x"])
         eng.base_forward(bp)
         self._x_key, self._bp, self._f_host = None, bp, None
@@ -130,10 +130,19 @@ class RPNModel(_ModelBase):
         """Device-resident twin of predict() + rpn.rpn_to_roi() for RADNet's tile path: uint8 BGR image on the device ->
         proposals (n,4) int64 x1,y1,x2,y2 in feature-map units on the host (a few KB) and the plans that hold the feature
         map on the device.  Same kernels as the NumPy-facing calls, so the same proposals."""
+        return self.propose_finish(self.propose_launch(img_dev, overlap_thresh, max_boxes))
+
+    def propose_launch(self, img_dev, overlap_thresh=0.7, max_boxes=300, slot=0):
+        """First half of propose_device: everything enqueued on the current lane, nothing read back."""
         eng = self._s.eng
-        bp = self._s.base_from_u8(img_dev)
+        bp = self._s.base_from_u8(img_dev, slot)
         rp = eng.rpn_forward(bp)
         R, Rn = eng.proposals(rp, overlap_thresh=overlap_thresh, max_boxes=max_boxes)
+        return R, Rn, bp
+
+    @staticmethod
+    def propose_finish(handle):
+        R, Rn, bp = handle
         n = int(Rn.cpu()[0])
         if n <= 0:
             raise ValueError("rpn_to_roi: no valid box")        # the reference's failed tuple-unpack (rpn.py:164-172)
@@ -223,7 +232,8 @@ class DetectorModel(_ModelBase):
         Fd.copy_(torch.from_numpy(F))
         return Fd, F.shape[1], F.shape[2]
 
-    def predict(self, inputs, **kw):
+    def predict_launch(self, inputs):
+        """First half of predict: the classifier pass enqueued on the current lane, nothing read back."""
         import torch
         eng = self._s.eng
         F, rois = inputs
@@ -235,7 +245,14 @@ class DetectorModel(_ModelBase):
         hp = eng._plan_head(rois.shape[0], fh, fw, Fd)
         hp["rois"].copy_(torch.from_numpy(rois))
         eng.head_forward(hp)
+        return hp
+
+    @staticmethod
+    def predict_finish(hp):
         return [hp["pcls"].cpu().numpy()[None], hp["pregr"].cpu().numpy()[None]]
+
+    def predict(self, inputs, **kw):
+        return self.predict_finish(self.predict_launch(inputs))
 
 
 class AllModel(_ModelBase):

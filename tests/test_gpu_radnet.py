@@ -261,3 +261,13 @@ def test_device_resident_detect_equals_numpy_facing_path(models):
         assert a.keys() == b.keys() and len(a) > 0
         for k in a:
             assert a[k][0] == b[k][0] and np.array_equal(np.array(a[k][1]), np.array(b[k][1]))
+    # two tiles in flight (side lane: upload .. proposals of tile j+1; main lane: classifier of tile j) == one at a time
+    tiles = [np.random.RandomState(70 + i).randint(0, 256, sh).astype(np.uint8) for i, sh in enumerate(((640, 640, 3), (640, 640, 3), (300, 420, 3), (640, 640, 3), (2048, 2048, 3)))]
+    net.device_resident = True
+    piped = net._detect_all(tiles)
+    one_by_one = [net._detect(t) for t in tiles]
+    assert len(piped) == len(tiles)
+    for a, b in zip(piped, one_by_one):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k][0] == b[k][0] and np.array_equal(np.array(a[k][1]), np.array(b[k][1]))

@@ -49,3 +49,13 @@ for mode in (False, True):
     dt = (time.perf_counter() - t0) / 20
     print("RADNet._detect, %s: %.2f ms per tile (%.1f tiles/s, %.1f TFLOP/s algorithmic at %.0f GF)" % (
         "device-resident" if mode else "NumPy-facing calls", dt * 1e3, 1 / dt, (58.95 + 15 * 29.29) / dt / 1e3 if C.img_size == 600 else float("nan"), 58.95 + 15 * 29.29))
+
+tiles = [np.random.RandomState(40 + i).randint(0, 256, (2048, 2048, 3)).astype(np.uint8) for i in range(8)]
+net.device_resident = True
+net._detect_all(tiles[:3])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+net._detect_all(tiles)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / len(tiles)
+print("RADNet._detect_all, 8 tiles, two in flight: %.2f ms per tile (%.1f tiles/s)" % (dt * 1e3, 1 / dt))
