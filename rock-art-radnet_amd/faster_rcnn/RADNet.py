@@ -173,20 +173,15 @@ class RADNet():
             X, ratio = self.format_img(img)
             Y1, Y2, F = self.model_rpn.predict(X)
             R = rpn.rpn_to_roi(Y1, Y2, self.C, overlap_thresh=0.7)
-        R[:, 2] -= R[:, 0]
-        R[:, 3] -= R[:, 1]
-        bboxes, probs = self.apply_spatial_pyramid_pooling(R, F)
-        out = {}
-        for key in bboxes:
-            nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
-            real = [self.get_real_coordinates(ratio, *nb[j, :]) for j in range(nb.shape[0])]
-            out[key] = (real, [npr[j] for j in range(nb.shape[0])])
-        return out
+        return self._finish_detect(R, F, ratio)
 
     def _finish_detect(self, R, F, ratio):
         R[:, 2] -= R[:, 0]
         R[:, 3] -= R[:, 1]
-        bboxes, probs = self.apply_spatial_pyramid_pooling(R, F)
+        return self._per_class_nms(*self.apply_spatial_pyramid_pooling(R, F), ratio)
+
+    def _per_class_nms(self, bboxes, probs, ratio):
+        """NMS 0.2 within each class, boxes back in source pixels (RADNet.py:562-575)."""
         out = {}
         for key in bboxes:
             nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
@@ -225,12 +220,7 @@ class RADNet():
                 nxt = launch(j + 1, done[(j + 1) % 2])
             pc, pr = self.model_detector.predict_finish(hp)
             bboxes, probs = self._spp_decode(chunks, [(pc[:, i * k:(i + 1) * k], pr[:, i * k:(i + 1) * k]) for i in range(len(chunks))])
-            det = {}
-            for key in bboxes:
-                nb, npr = rpn.non_max_suppression_fast(np.array(bboxes[key]), np.array(probs[key]), overlap_thresh=0.2)
-                real = [self.get_real_coordinates(ratio, *nb[i, :]) for i in range(nb.shape[0])]
-                det[key] = (real, [npr[i] for i in range(nb.shape[0])])
-            out.append(det)
+            out.append(self._per_class_nms(bboxes, probs, ratio))
         return out
 
     def predict(self, images):
