@@ -159,8 +159,7 @@ def main():
     else:
         eng = FasterRCNNEngine(C, device_index=local_rank)
         eng.set_weights(synth.synthetic_weights(seed=3))
-        _defer = os.environ.get("RADNET_BENCH_DEFER")          # experiment knob: force the deferred / immediate head update
-        ts = TrainStep(eng, world_size=world, defer_head_update=(_defer == "1") if _defer is not None else (True if nccl1 else None))
+        ts = TrainStep(eng, world_size=world, defer_head_update=True if nccl1 else None)
     have_cache = args.tune_cache is not None and os.path.exists(args.tune_cache)
     if have_cache:
         eng.load_tuning(args.tune_cache)
@@ -224,8 +223,6 @@ def main():
         for _ in range(6):          # every buffer set once
             ts.step(batch)
         torch.cuda.synchronize()
-        if os.environ.get("RADNET_ROOFLINE_SLEEP"):      # experiment knob
-            time.sleep(float(os.environ["RADNET_ROOFLINE_SLEEP"]))
         eng.ctx.timing(True)
         eng.ctx.timing_reset()
         eng.wino_timing[:] = [0.0, 0.0, 0]
