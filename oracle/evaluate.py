@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's evaluation tail (test.py:48-173, 242-264), plain loops.
 
-Parity unpinned: test.py imports cv2 / TensorFlow / matplotlib at module level and cannot be imported here, so no golden
-vectors exist for these functions; the restatement follows the source text line by line (citations below) and the product
-(faster_rcnn/evaluate.py, vectorised) is tested against it plus hand-computed cases.  Nothing under
+Parity PINNED for get_objects / calc_class_ap: tools/gen_golden_scripts.py imports the reference's test.py (empty stubs for
+cv2 / tensorflow / keras / matplotlib.pyplot, none of which these functions touch) and records their outputs in
+tests/golden/voc_ap.json; tests/test_script_goldens.py checks this restatement and the product (faster_rcnn/evaluate.py,
+vectorised) against them.  The flip / 90-degree augmentation loops below stay unpinned (cv2.flip cannot run here).  Nothing under
 rock-art-radnet_amd/ imports this file.
 """
 import numpy as np

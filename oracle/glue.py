@@ -4,8 +4,8 @@ cpu_baseline leg may import this module; the shipped path is the HIP library.
 
 Parity status: PINNED -- every function here is checked bit-for-bit against vectors
 produced by importing the reference itself (tools/gen_golden.py -> tests/golden/*.npz),
-except `select_samples`, whose reference lives in train.py (imports TensorFlow, cannot
-be imported here): that one is "parity unpinned", restated from train.py:93-129.
+including `select_samples` (train.py:93-129): train.py is imported with empty stubs for its absent
+third-party imports by tools/gen_golden_scripts.py -> tests/golden/selected_samples.json.
 
 All citations are relative to the reference tree (faster_rcnn/...).
 The arithmetic is IEEE double unless stated; where the reference mixes fp32 in
@@ -224,7 +224,7 @@ def roi_targets(R, gt_boxes, gt_cls, width, height, C):
 
 
 def select_samples(Y1, n_rois):
-    """train.py:93-129 (parity unpinned: train.py cannot be imported without TensorFlow).
+    """train.py:93-129 (pinned: tests/golden/selected_samples.json, tests/test_script_goldens.py).
     Consumes the global NumPy RNG exactly as the reference does."""
     neg = np.where(Y1[0, :, -1] == 1)[0]
     pos = np.where(Y1[0, :, -1] == 0)[0]

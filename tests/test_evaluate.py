@@ -1,6 +1,5 @@
 """Evaluation tail (test.py:48-173, 242-264): the product's vectorised implementation against the loop
-restatement in oracle/evaluate.py and hand-computed cases.  Parity unpinned against the reference (test.py needs cv2 /
-TensorFlow to import)."""
+restatement in oracle/evaluate.py and hand-computed cases.  The reference's own outputs are checked in tests/test_script_goldens.py."""
 import copy
 
 import numpy as np

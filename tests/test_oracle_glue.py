@@ -88,7 +88,7 @@ def test_anchor_targets():
 
 
 def test_select_samples_contract():
-    # parity unpinned (train.py:93-129 cannot be imported); contract checks only
+    # contract checks; the reference's own outputs: tests/test_script_goldens.py
     C = Config()
     np.random.seed(5)
     Y1 = np.zeros((1, 50, 7)); Y1[0, :, -1] = 1; Y1[0, :4, -1] = 0; Y1[0, :4, 0] = 1
