@@ -4,8 +4,9 @@
 // PARITY UNPINNED: OpenCV is absent from this image and the reference ships no resized fixture, so this follows
 // OpenCV's documented algorithm for 8-bit images (bicubic kernel a = -0.75, half-pixel centres
 // src = (dst + 0.5) * scale - 0.5, replicated borders, 11-bit fixed-point coefficients, horizontal pass into
-// 32-bit integers then vertical pass with a single rounding shift of 22 bits and saturation) without a way to
-// check it bit-for-bit here.
+// 32-bit integers then vertical pass with a single rounding shift of 22 bits and saturation).  What CAN be checked is
+// checked: bit-for-bit against the independent NumPy restatement of that algorithm in oracle/resize.py
+// (tests/test_gpu_resize.py).  Compiled with -ffp-contract=off: the float32 weight polynomials must round as written.
 #include "radnet_internal.h"
 
 namespace {
@@ -27,7 +28,7 @@ __device__ __forceinline__ void cubic_coeffs(float x, short* c) {
 __global__ void __launch_bounds__(256) resize_bicubic_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst, int dh,
                                                                 int dw, int ch) {
   const long long total = (long long)dh * dw;
-  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);      // OpenCV: 1. / inv_scale
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int dx = (int)(idx % dw), dy = (int)(idx / dw);
     float fx = (float)((dx + 0.5) * scale_x - 0.5);

@@ -87,6 +87,8 @@ class TrainStep:
         # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
         self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "lane")
         self.skipped_head_steps = 0
+        self.dropped_images = 0     # images whose anchor labelling raised (reference: sample skipped, utils.py:461-465)
+        self.on_drop = None         # optional callback(sample, exception); default: one line on stderr, like the reference's print
         self.last = None
         self.capture = None         # set to [] to record per-image intermediates (tests: stage-wise parity)
         self.host_marks = None      # set to [] to record (label, perf_counter) at the host-side phase boundaries
@@ -163,23 +165,52 @@ class TrainStep:
         batch, plans, rps, slot = st["batch"], st["plans"], st["rps"], st["slot"]
         nloc = len(batch)
         # gradient arenas are zero here: allocated zeroed, and every Adam pass clears what it consumed
+        # The labeller can fail exactly where the reference's does (KeyError while building the subsampling probabilities,
+        # utils.py:789-797): the reference swallows that inside its generator (utils.py:461-465, `except: continue`) and the
+        # image never reaches the model -- no optimizer effect, no draw from the RNG.  Same here: the image is dropped from
+        # this batch before anything of it touches a gradient; the rest of the batch, and the head phase of the batch before
+        # it (pipelined mode), go on.
+        dead = st["dead"] = [False] * nloc
+        n_live = 0
         for i in range(nloc):
-            ycls, yregr, _ = eng.anchor_targets_finish(st["tp"][i])
+            try:
+                ycls, yregr, _ = eng.anchor_targets_finish(st["tp"][i])
+            except KeyError as e:
+                dead[i] = True
+                self.dropped_images += 1
+                self._report_drop(batch[i], e)
+                continue
             mark("A: label maps on host, subsampled, packed")
-            eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
+            eng.set_accumulate(rps[i]["bwd"], n_live > 0, prezeroed=True)
             eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[slot][i])
+            n_live += 1
+        st["roi"] = [None] * nloc
+        if n_live == 0 and self.world == 1 and not FORCE_COLLECTIVES:
+            st["adam1"] = eng.mark() if hasattr(eng, "mark") else None
+            return                                     # whole batch dropped: no Adam step at all (the reference trains nothing)
+        # world > 1: a rank whose images were all dropped still joins the exchange (zeros) and applies the same update as
+        # its peers (replicas stay identical); the mean stays over the nominal batch, a dropped image contributing zero
         self._allreduce(eng.rpn_arena)
         eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
         st["adam1"] = eng.mark() if hasattr(eng, "mark") else None
         mark("C: rpn backward + adam enqueued")
-        st["roi"] = []
         for i, bp in enumerate(plans):
+            if dead[i]:
+                continue
             s = batch[i]
             eng._run(rps[i].get("refwd", rps[i]["fwd"]))      # same feature map as the first pass: no second input transform
             R, Rn = eng.proposals(rps[i], overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
-            st["roi"].append((R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i)))
+            st["roi"][i] = (R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i))
         mark("D: rpn re-predict + proposals + roi targets enqueued")
+
+    def _report_drop(self, sample, exc):
+        if self.on_drop is not None:
+            self.on_drop(sample, exc)
+        else:
+            import sys
+            sys.stderr.write("radnet: anchor labelling failed (%s: %s); sample skipped as the reference's generator does\n"
+                             % (type(exc).__name__, exc))
 
     def step(self, batch, next_batch=None, after_next=None, upcoming=None):
         """batch: list of dicts {img: uint8 BGR HWC (already at network size), bboxes: [{class,x1,x2,y1,y2}],
@@ -269,6 +300,9 @@ class TrainStep:
         # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
         picks = []
         for i in range(nloc):
+            if st["roi"][i] is None:                               # dropped by the labeller (see _rpn_phase): not a head skip
+                picks.append(None)
+                continue
             R, P = st["roi"][i]
             P, cls, n = eng.roi_targets_finish(P)
             mark("D: roi classes on host")
@@ -332,15 +366,16 @@ class TrainStep:
             if lanes:
                 self._head_last = self._head_done[slot] = eng.mark()
         mark("D: head forward + backward + adam enqueued")
-        self.last = (nloc, n_head, slot)
+        self.last = (nloc, n_head, slot, list(st.get("dead", [False] * nloc)))
         return self
 
     def losses(self):
         """Host copy of the last step's mean losses (one device sync)."""
-        nloc, n_head, slot = self.last
+        nloc, n_head, slot, dead = self.last
         if self._head_last is not None:
             self._head_last.synchronize()            # the head lane wrote the detector losses
-        r = self._rpn_l[slot][:nloc].cpu().numpy().mean(0)
+        live = [i for i in range(nloc) if not dead[i]]
+        r = self._rpn_l[slot][:nloc].cpu().numpy()[live].mean(0) if live else np.full(2, np.nan, np.float32)
         d = self._det_l[slot][:max(n_head, 1)].cpu().numpy().mean(0) if n_head else np.zeros(3, np.float32)
         return {"rpn_cls": float(r[0]), "rpn_regr": float(r[1]), "det_cls": float(d[0]), "det_regr": float(d[1]), "det_acc": float(d[2]),
-                "n_head": n_head}
+                "n_head": n_head, "dropped": nloc - len(live)}

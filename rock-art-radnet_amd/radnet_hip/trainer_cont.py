@@ -26,6 +26,7 @@ class ContTrainStep:
         self.world = world_size
         self.group = dist_group
         self.skipped_head_steps = 0
+        self.dropped_images = 0
         self.last = None
         self.capture = None
         dev = eng.dev
@@ -80,12 +81,25 @@ class ContTrainStep:
             eng.s34_forward(bp)
             rps.append(eng.rpn_forward(bp))
         # ---- RPN model: loss, gradients of the RPN convs and (via dL/dF) of stages 3-4, Adam #1 over both
+        dead = [False] * nloc          # labeller failures: the reference's generator skips such a sample (utils.py:461-465)
+        n_live = 0
         for i in range(nloc):
-            ycls, yregr, _ = eng.anchor_targets_finish(tp[i])
-            eng.set_accumulate(rps[i]["bwd"], i > 0, prezeroed=True)
-            eng.set_accumulate(plans[i]["bwd34"], i > 0, prezeroed=True)
+            try:
+                ycls, yregr, _ = eng.anchor_targets_finish(tp[i])
+            except KeyError as e:
+                import sys
+                sys.stderr.write("radnet: anchor labelling failed (KeyError: %s); sample skipped as the reference's generator does\n" % (e,))
+                dead[i] = True
+                self.dropped_images += 1
+                continue
+            eng.set_accumulate(rps[i]["bwd"], n_live > 0, prezeroed=True)
+            eng.set_accumulate(plans[i]["bwd34"], n_live > 0, prezeroed=True)
             eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[i])      # ends with rpn_conv1's dgrad into plan['dF']
             eng.s34_backward(plans[i])
+            n_live += 1
+        if n_live == 0 and self.world == 1:
+            self.last = (nloc, 0, dead)
+            return self                                # whole batch dropped: no optimizer step
         allreduce_grad_arena(eng.rpn_arena.g, self.world, self.group)
         allreduce_grad_arena(eng.s34_arena.g, self.world, self.group)
         eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
@@ -93,6 +107,8 @@ class ContTrainStep:
         # ---- classifier model on the moved base
         n_head = 0
         for i, bp in enumerate(plans):
+            if dead[i]:
+                continue
             s = batch[i]
             rp = rps[i]
             eng.s34_forward(bp)
@@ -123,12 +139,13 @@ class ContTrainStep:
             eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
             eng.refresh_head_shift()
             eng.adam_s34(1, grad_scale=1.0 / ntot)
-        self.last = (nloc, n_head)
+        self.last = (nloc, n_head, dead)
         return self
 
     def losses(self):
-        nloc, n_head = self.last
-        r = self._rpn_l[:nloc].cpu().numpy().mean(0)
+        nloc, n_head, dead = self.last
+        live = [i for i in range(nloc) if not dead[i]]
+        r = self._rpn_l[:nloc].cpu().numpy()[live].mean(0) if live else np.full(2, np.nan, np.float32)
         d = self._det_l[:max(n_head, 1)].cpu().numpy().mean(0) if n_head else np.zeros(3, np.float32)
         return {"rpn_cls": float(r[0]), "rpn_regr": float(r[1]), "det_cls": float(d[0]), "det_regr": float(d[1]), "det_acc": float(d[2]),
-                "n_head": n_head}
+                "n_head": n_head, "dropped": nloc - len(live)}

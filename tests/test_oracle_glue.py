@@ -144,3 +144,20 @@ def test_merge_nms_and_real_coords():
         assert np.array_equal(b, g[f"c{i}_out_boxes"]) and np.array_equal(p, g[f"c{i}_out_probs"])
     out = np.array([[glue.real_coords(r, *[int(v) for v in c]) for c in g["grc_in"]] for r in g["grc_ratios"]])
     assert np.array_equal(out, g["grc_out"])
+
+
+def test_resize_oracle_vectorised_equals_pixel_loops():
+    """oracle/resize.py: the two-pass vectorised restatement of the 8-bit INTER_CUBIC definition == the plain integer loops
+    (parity vs cv2 itself unpinned: OpenCV absent); identity size reproduces the input; constant images stay constant."""
+    from oracle import resize as R
+    rs = np.random.RandomState(5)
+    for (h, w, nh, nw, c) in [(7, 9, 5, 4, 3), (3, 2, 7, 9, 3), (1, 1, 4, 4, 1), (5, 5, 5, 5, 3), (2, 3, 1, 1, 4), (12, 17, 30, 23, 3)]:
+        img = rs.randint(0, 256, (h, w, c)).astype(np.uint8)
+        a = R.resize_bicubic_u8(img, nw, nh)
+        assert np.array_equal(a, R.resize_bicubic_u8_loops(img, nw, nh))
+        if (h, w) == (nh, nw):
+            assert np.array_equal(a, img)
+    flat = np.full((9, 11, 3), 143, np.uint8)
+    assert (R.resize_bicubic_u8(flat, 31, 17) == 143).all()
+    idx, wi = R._axis_tables(2048, 600)
+    assert (wi.sum(1) >= 2047).all() and (wi.sum(1) <= 2049).all() and idx.min() == 0 and idx.max() == 2047
