@@ -8,6 +8,7 @@ Inputs (uint8 panels, GT boxes) are resident before the timed region; the panel 
 from pinned host memory exactly as the reference feeds its model (the PCIe copy is inside the step).
 
   python bench.py --gpus 1 --steps 300 --warmup 30
+  python bench.py --gpus N ...          (no launcher: starts its N ranks itself, one per GPU -- radnet_hip/launch.py)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -91,14 +92,36 @@ def main():
                          "unfrozen in both models (secondary measurement, single GPU)")
     ap.add_argument("--tune-cache", default=None,
                     help="file with measured GEMM launch choices: loaded when present (no trial launches), written after warm-up otherwise")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, form the process group over gloo (no GPU), all-reduce the ranks, print one JSON line: "
+                         "exercises the self-launch path on a machine without GPUs (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process has made no GPU call (torch is imported, nothing
+        # initialised) -- it starts N fresh rank processes, one per GPU, relays rank 0's JSON line and exits with their code
+        from radnet_hip.launch import spawn_ranks
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                              "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     dist = None
     nccl1 = os.environ.get("RADNET_BENCH_REHEARSAL") == "nccl1" and world == 1
     if nccl1:
@@ -222,12 +245,14 @@ def main():
         # a host-synchronous upload that would otherwise sit between a launch's two events).
         for _ in range(6):          # every buffer set once
             ts.step(batch)
+        ts.flush()
         torch.cuda.synchronize()
         eng.ctx.timing(True)
         eng.ctx.timing_reset()
         eng.wino_timing[:] = [0.0, 0.0, 0]
         for _ in range(args.roofline_steps):
             ts.step(batch)
+        ts.flush()                    # data-parallel: the last deferred head update must not be left pending
         torch.cuda.synchronize()
         per = {}
         tot_ms = tot_fl = 0.0

@@ -286,11 +286,31 @@ def resize_cubic(img, new_w, new_h, to_host=True, ctx=None):
     return dst if not to_host else dst.cpu().numpy()
 
 
+class _ConfigUnpickler(pickle.Unpickler):
+    """config.pickle holds a plain attribute bag (config.py:5-133; train.py:176-180 dumps it): only that class and builtin
+    containers / scalars are admitted, so a crafted file cannot name arbitrary callables (the reference's bare
+    pickle.load, RADNet.py:724, would execute them)."""
+    _BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "complex", "slice", "range"}
+
+    def find_class(self, module, name):
+        if (module, name) == ("faster_rcnn.config", "Config"):
+            from .config import Config
+            return Config
+        if module == "builtins" and name in self._BUILTINS:
+            import builtins
+            return getattr(builtins, name)
+        if (module, name) == ("collections", "OrderedDict"):
+            import collections
+            return collections.OrderedDict
+        raise pickle.UnpicklingError("config pickle refers to %s.%s: only faster_rcnn.config.Config and builtin containers are loaded"
+                                     % (module, name))
+
+
 def load_radnet(config_path, device_index=0):
     """RADNet.py:721-775: unpickle the Config, build the RPN (3 outputs) and detector models, load C.weights_path."""
     from . import models
     with open(config_path, 'rb') as f:
-        C = pickle.load(f)
+        C = _ConfigUnpickler(f).load()
     if C.network == 'resnet50':
         from .base_models import resnet50 as base_model
     elif C.network == 'vgg16':

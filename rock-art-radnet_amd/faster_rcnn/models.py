@@ -242,7 +242,7 @@ class DetectorModel(_ModelBase):
         else:
             Fd, fh, fw = self._features(F)
         rois = np.asarray(rois, dtype=np.float32).reshape(-1, 4)
-        hp = eng._plan_head(rois.shape[0], fh, fw, Fd)
+        hp = eng._plan_head(rois.shape[0], fh, fw, Fd, training=False)
         hp["rois"].copy_(torch.from_numpy(rois))
         eng.head_forward(hp)
         return hp

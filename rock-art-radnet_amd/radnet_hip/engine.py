@@ -11,6 +11,7 @@ Graph restated from the reference (never imported):
   head   faster_rcnn/base_models/resnet50.py:231-281   RoI crop-resize 14x14 + stage 5 + avgpool + dense
   step   train.py:288-402                              RPN train -> re-predict -> propose/label/sample -> head train
 """
+import collections
 import ctypes as C
 import contextlib
 import os
@@ -75,6 +76,32 @@ class Arena:
         return self.views["d:" + name]
 
 
+class PlanCache(collections.OrderedDict):
+    """Layer plans keyed by (kind, shape..., buffer set / feature-map pointer), least-recently-used first.  Every distinct
+    image / tile shape and RoI count allocates a plan (activation buffers, descriptors, recorded hipGraphs): a long
+    predict run over variable-size inputs would otherwise grow device memory without bound.  At most `limit` plans per
+    kind stay; the oldest is dropped through `on_evict` (the engine waits for the device, then forgets its graphs)."""
+
+    def __init__(self, limit, on_evict):
+        super().__init__()
+        self.limit, self.on_evict = limit, on_evict
+
+    def __getitem__(self, key):
+        v = super().__getitem__(key)
+        self.move_to_end(key)
+        return v
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self.move_to_end(key)
+        same = [k for k in self if k[0] == key[0]]
+        while len(same) > self.limit:
+            old = same.pop(0)
+            value = collections.OrderedDict.__getitem__(self, old)
+            collections.OrderedDict.__delitem__(self, old)
+            self.on_evict(old, value)
+
+
 class ConvLayer:
     """One convolution of the static layer program (descriptor prebuilt; pointers are stable)."""
 
@@ -115,9 +142,13 @@ class FasterRCNNEngine:
         self.lr = lr
         if 5 * self.A > RPN_LD:
             raise L.RadnetError("engine: %d anchors exceed the fused RPN head width" % self.A)
+        if self.nc + self.nreg > 64:
+            raise L.RadnetError("engine: %d classes need %d dense-head columns, the fused dense-head kernel holds 64 (at most 13 classes)"
+                                % (self.nc, self.nc + self.nreg))
         self.dense_ld = 32 if self.nc + self.nreg <= 32 else 64
         self._build_layers()
-        self._plans = {}
+        # 32 per kind: the training step keeps 6 buffer sets x images per GPU alive at once; beyond that, least recently used
+        self._plans = PlanCache(int(os.environ.get("RADNET_PLAN_CACHE", "32")), self._evict_plan)
         self._graphs = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
@@ -423,6 +454,18 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
+    def _evict_plan(self, key, plan):
+        """A plan leaves the cache: nothing may still be reading its buffers (lanes run ahead of the host), and the
+        hipGraphs recorded from its launch lists go with it."""
+        torch.cuda.synchronize(self.dev)
+        lists = set()
+        for v in plan.values():
+            if isinstance(v, list):
+                lists.add(id(v))
+                lists.update(id(p[0]) for p in v if isinstance(p, tuple) and p and isinstance(p[0], list))     # bwd_parts
+        for gk in [k for k in self._graphs if k[0] in lists]:
+            del self._graphs[gk]
+
     def save_tuning(self, path):
         """Write the measured GEMM launch choices of this engine (one table for all lanes) to a text file."""
         self.ctx.check(self.lib.radnet_tune_save(self.ctx.h, path.encode()), "radnet_tune_save")
@@ -720,8 +763,10 @@ class FasterRCNNEngine:
         return rp["R"], rp["Rn"]
 
     # ------------------------------------------------------------------------------------------ classifier head
-    def _plan_head(self, R, fh, fw, F):
-        key = ("head", R, fh, fw, F.data_ptr())
+    def _plan_head(self, R, fh, fw, F, training=True):
+        """training=False (DetectorModel.predict / RADNet's tile path): forward buffers only -- the backward program's
+        gradient buffers (~1.4 GB at R = 300) are not allocated for a plan that never differentiates."""
+        key = ("head" if training else "head_inf", R, fh, fw, F.data_ptr())
         if key in self._plans:
             return self._plans[key]
         dev = self.dev
@@ -756,6 +801,11 @@ class FasterRCNNEngine:
         feat = buf(R, 2048)
         pcls, pregr = buf(R, self.nc), buf(R, self.nreg)
         y1, y2 = buf(R, self.nc), buf(R, 2 * self.nreg)
+        if not training:
+            plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls, pregr=pregr,
+                        F=F, fh=fh, fw=fw, keep=keep)
+            self._plans[key] = plan
+            return plan
         dz = buf(R, self.nc + self.nreg)
         dfeat = buf(R, 2048)
         # backward program (train.py mode: nothing flows below the RoI crop, the base is frozen)

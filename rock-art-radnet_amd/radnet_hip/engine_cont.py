@@ -219,8 +219,10 @@ class ContEngine(FasterRCNNEngine):
         return rp
 
     # ------------------------------------------------------------------------------------------ head: continue into dF
-    def _plan_head(self, R, fh, fw, F):
-        hp = super()._plan_head(R, fh, fw, F)
+    def _plan_head(self, R, fh, fw, F, training=True):
+        hp = super()._plan_head(R, fh, fw, F, training)
+        if not training:
+            return hp
         if "pool_bwd" not in hp:
             base = self._base_of_F[F.data_ptr()]
             B = hp["blocks"][0]                                          # res5a: stride-2 2a and shortcut read the pooled RoIs

@@ -170,7 +170,7 @@ class VGG16Engine(FasterRCNNEngine):
         d.ldw, d.ldy, d.ld_add, d.act, d.act_cols = c.cout, c.cout, c.cout, 1 if relu else 0, 0
         return d
 
-    def _plan_head(self, R, fh, fw, F):
+    def _plan_head(self, R, fh, fw, F, training=True):       # (one plan form: the fc head's buffers are small)
         key = ("head", R, fh, fw, F.data_ptr())
         if key in self._plans:
             return self._plans[key]

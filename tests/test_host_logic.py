@@ -80,3 +80,18 @@ def test_synthetic_weights_equal_oracle_init():
 def test_feature_size_formula():
     for L in (600, 800, 1000, 2000, 333, 240):
         assert E.feat_len(L) == glue.resnet50_feat_len(L)
+
+
+def test_plan_cache_is_bounded_per_kind():
+    """engine.PlanCache: least-recently-used plans of a kind are evicted beyond the limit; other kinds are untouched."""
+    from radnet_hip.engine import PlanCache
+    gone = []
+    pc = PlanCache(3, lambda k, v: gone.append(k))
+    for i in range(3):
+        pc[("head", i)] = {"i": i}
+    pc[("base", 0)] = {}
+    assert pc[("head", 0)]["i"] == 0                 # touch: ("head", 1) is now the oldest head plan
+    pc[("head", 3)] = {}
+    assert gone == [("head", 1)] and ("head", 0) in pc and ("base", 0) in pc and len(pc) == 4
+    pc[("head", 4)] = {}
+    assert gone == [("head", 1), ("head", 2)]

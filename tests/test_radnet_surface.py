@@ -1,6 +1,7 @@
 """RADNet facade (drop-in surface) driven with the closed-form fake models the golden generator used on the
 reference's own RADNet class: host-side parts only (no GPU)."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 from faster_rcnn.config import Config
@@ -59,3 +60,26 @@ def test_surface_attributes():
     assert (net.is_object_threshold, net.bbox_threshold) == (0.5, 0.7)
     assert net.class_mapping == {v: k for k, v in C.class_mapping.items()}
     assert net.model_rpn == "rpn" and net.model_detector == "det" and net.preprocess_func == "prep"
+
+
+def test_config_unpickler_admits_config_only(tmp_path):
+    """load_radnet reads config.pickle (RADNet.py:724) through a restricted unpickler: a Config round-trips (including the
+    attributes train.py adds dynamically), a pickle naming any other callable is refused before it can run."""
+    import io
+    import pickle
+
+    from faster_rcnn.RADNet import _ConfigUnpickler
+    from faster_rcnn.config import Config
+    C = Config()
+    C.weights_path = "models/x/weights.hdf5"            # train.py:174
+    C.class_mapping = dict(C.class_mapping)
+    back = _ConfigUnpickler(io.BytesIO(pickle.dumps(C))).load()
+    assert isinstance(back, Config) and back.__dict__ == C.__dict__
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    with pytest.raises(pickle.UnpicklingError):
+        _ConfigUnpickler(io.BytesIO(pickle.dumps(Evil()))).load()
+    assert not (tmp_path / "pwned").exists()
