@@ -75,6 +75,97 @@ def cpu_baseline(budget_s=25.0):
             "sample": "%d full train iterations (1000x600, 8 GT, NumPy/BLAS oracle, fp32) in %.1f s" % (n, dt)}
 
 
+class _Ptr:
+    """int device address with the tensor method the engine's descriptor builder calls."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def data_ptr(self):
+        return self.p
+
+
+def _time_us(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def layers_3x3_table(eng, bp, rp):
+    """north_star target "MFMA utilisation on ResNet50 stage-3/4 3x3 convs" (+ rpn_conv1), per layer class, each form alone on
+    the chip, back-to-back launches between two HIP events on the launch stream: the Winograd F(2x2,3x3) form the step runs
+    (input transform + 16 batched GEMMs + output transform with BN/ReLU) and the direct implicit GEMM.  `executed` = flops the
+    MFMAs really perform (Winograd: 2*16*tiles*C*N), `algorithmic` = 2*M*N*9C; fractions are of 157.3 TFLOP/s."""
+    import ctypes as C
+    lib = eng.lib
+    rows = []
+    wanted = {"res3b_branch2b": "stage-3 3x3 128->128 (res3a-d_branch2b)", "res4b_branch2b": "stage-4 3x3 256->256 (res4a-f_branch2b)",
+              "rpn_conv1": "rpn_conv1 3x3 1024->512"}
+    found = {}
+    for kind, p in list(bp["ops"]) + list(rp["fwd"]):
+        if kind != "wino":
+            continue
+        for name in wanted:
+            c = eng.convs[name]
+            if p[7] == c.wino_u.data_ptr():
+                found[name] = p
+    for name, label in wanted.items():
+        if name not in found:
+            continue
+        c = eng.convs[name]
+        x, nb, hh, ww, cin, n, V, U, M, T, scale, shift, act, y, ldy = found[name]
+        h = eng.ctx.h
+        t_in = _time_us(lambda: lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V))
+        t_g = _time_us(lambda: lib.radnet_gemm_batched(h, V, U, M, 16, T, n, cin))
+        t_out = _time_us(lambda: lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy))
+
+        def layer():
+            lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V)
+            lib.radnet_gemm_batched(h, V, U, M, 16, T, n, cin)
+            lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
+        t_layer = _time_us(layer)
+        d, _, _ = eng._desc(c, _Ptr(x), nb, hh, ww, _Ptr(y), relu=bool(act))
+        t_dir = _time_us(lambda: lib.radnet_conv_fwd(h, C.byref(d)))
+        algo = 2.0 * nb * hh * ww * n * 9 * cin
+        execd = 2.0 * 16 * T * cin * n
+        rows.append({"layer": label, "M": nb * hh * ww, "N": n, "K": 9 * cin, "tiles": T,
+                     "winograd_us": {"input_transform": t_in, "gemm_16x": t_g, "output_transform": t_out, "layer_back_to_back": t_layer},
+                     "direct_us": t_dir, "algorithmic_gflop": algo / 1e9, "winograd_executed_gflop": execd / 1e9,
+                     "winograd_gemm_executed_tflops": execd / t_g / 1e6, "winograd_gemm_executed_frac": execd / t_g / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                     "winograd_layer_algorithmic_tflops": algo / t_layer / 1e6, "winograd_layer_algorithmic_frac": algo / t_layer / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                     "direct_tflops": algo / t_dir / 1e6, "direct_frac": algo / t_dir / 1e6 / PEAK_FP32_MFMA_TFLOPS})
+    return rows
+
+
+def collectives_leg(eng, ts, dist, world, n=20):
+    """Data-parallel exchanges alone on the chip (after the timed region): bytes and time of the two gradient all-reduces of
+    a step, as the step issues them (AR#1 whole RPN arena on its communicator; AR#2 = three kernel-gradient buckets + tail
+    on the head communicator)."""
+    if dist is None:
+        return None
+    out = {"per_step": "AR#1 rpn arena (1 call) + AR#2 head arena (3 block buckets + tail)", "world": world}
+    for name, arena, group in (("ar1_rpn", eng.rpn_arena, ts.group), ("ar2_head", eng.head_arena, ts.group_head)):
+        buf = torch.zeros_like(arena.g)
+        for _ in range(3):
+            dist.all_reduce(buf, group=group)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            dist.all_reduce(buf, group=group)
+        e1.record()
+        e1.synchronize()
+        out[name] = {"bytes": int(arena.n * 4), "ms_alone": e0.elapsed_time(e1) / n}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,10 +362,23 @@ def main():
                                               "tflops": wfl / max(wms, 1e-9) / 1e9}
             tot_ms += wms; tot_fl += wfl
         ach = tot_fl / max(tot_ms, 1e-9) / 1e9
+        # executed flops: what the MFMAs really performed (Winograd layers execute 16*tiles*C*N*2 = 1/2.25 of their credit)
+        exec_fl = tot_fl - (wfl - wfl / 2.25 if wn else 0.0)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
+                "schedule": "one lane, launches isolated (each GEMM launch alone on the chip between two HIP events); `value` is measured on the "
+                            "pipelined schedule, where lanes overlap -- gemm_ms_per_image here may exceed ms_per_step",
+                "winograd_credit": "Winograd layers are timed per layer (3 kernels) and credited the algorithmic 2*M*N*9C flops, not the 2.25x fewer they execute",
+                "executed_tflops": exec_fl / max(tot_ms, 1e-9) / 1e9, "executed_frac": exec_fl / max(tot_ms, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,
                 "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}
+        if rank == 0 and not cont and hasattr(eng, "_plan_rpn"):
+            try:
+                bp0 = eng._plan_base(1, args.height, args.width, 0)
+                roof["layers_3x3"] = layers_3x3_table(eng, bp0, eng._plan_rpn(bp0["fh"], bp0["fw"], bp0["F"]))
+            except Exception as e:                       # a secondary table must never cost the bench line
+                roof["layers_3x3_error"] = repr(e)
+    coll = collectives_leg(eng, ts, dist, world) if (dist is not None and not cont) else None
     if dist is not None:
         dist.barrier()
 
@@ -287,8 +391,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full train step (RPN + RoiPoolingConv + classifier head + losses + 2x Adam), ResNet50, %dx%d, "
-                                   "batch=%d per GPU, %s" % (args.width, args.height, args.per_gpu_batch,
-                                                              "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
+                                   "batch=%d per GPU, %s; identical panel and boxes on every rank and step (per-rank RNG seed)"
+                                   % (args.width, args.height, args.per_gpu_batch,
+                                      "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
                        "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
                        "parallelism": "dp%d" % world,
                        "schedule": ("one lane" if cont or not getattr(ts, "side_prefetch", False) else
@@ -300,6 +405,8 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+        if coll is not None:
+            out["config"]["collectives"] = coll
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -80,21 +80,40 @@ class _ModelBase:
             self._s.eng.lr = self._lr
 
     def save_weights(self, path):
+        """model_all.save_weights (train.py:574).  '*.h5' / '*.hdf5' -> a Keras-2 HDF5 weights file (layer groups, weight_names
+        attributes: faster_rcnn/keras_h5.py, no h5py needed); anything else -> '<path>.npz' with keys '<layer>/<param>'."""
         self._s.sync_weights_from_engine()
+        path = str(path)
+        if path.endswith((".h5", ".hdf5")):
+            from . import keras_h5
+            keras_h5.write_keras_weights(path, self._s.W)
+            return
         flat = {"%s/%s" % (n, k): v for n, d in self._s.W.items() for k, v in d.items()}
-        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **flat)
+        np.savez(path if path.endswith(".npz") else path + ".npz", **flat)
 
     def load_weights(self, path, by_name=True):
+        """model.load_weights(path, by_name=True) (RADNet.py:754,769; cont_train.py:155,164): layers are matched by NAME, layers
+        of the file this model does not have are skipped, layers of the model the file lacks keep their weights.  Keras HDF5
+        files (recognised by their signature, whatever the suffix) and this package's .npz files."""
         path = str(path)
         if not os.path.exists(path) and os.path.exists(path + ".npz"):
             path += ".npz"
-        if path.endswith((".h5", ".hdf5")) and not path.endswith(".npz"):
-            raise NotImplementedError("Keras HDF5 weight files need h5py, which is absent here: convert them to the .npz layout "
-                                      "(keys '<layer>/<param>') first -- SURVEY.md 8f N1")
-        z = np.load(path, allow_pickle=False)
-        for key in z.files:
-            n, k = key.rsplit("/", 1)
-            self._s.W.setdefault(n, {})[k] = z[key]
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        from . import keras_h5
+        if magic == keras_h5.SIGNATURE:
+            loaded = keras_h5.load_weights_by_name(path, known_layers=set(self._s.W))
+            for n, d in loaded.items():
+                for k, v in d.items():
+                    if k in self._s.W[n] and tuple(np.shape(self._s.W[n][k])) != tuple(v.shape):
+                        raise ValueError("load_weights: layer %r %s has shape %s in the file, the model expects %s"
+                                         % (n, k, v.shape, np.shape(self._s.W[n][k])))
+                self._s.W[n].update(d)
+        else:
+            z = np.load(path, allow_pickle=False)
+            for key in z.files:
+                n, k = key.rsplit("/", 1)
+                self._s.W.setdefault(n, {})[k] = z[key]
         self._s.eng.set_weights(self._s.W)
         self._s._x_key = None
 

@@ -176,8 +176,22 @@ def test_save_load_weights_roundtrip(models, tmp_path):
     m_all.load_weights(path, by_name=True)
     b = m_rpn3.predict(X)
     assert all(np.array_equal(u, v) for u, v in zip(a, b))
-    with pytest.raises(NotImplementedError):
-        m_all.load_weights(str(tmp_path / "weights.hdf5"))
+    # Keras HDF5 weights (train.py:574 save_weights / RADNet.py:754,769 load_weights(by_name=True)); parity vs h5py unpinned
+    from faster_rcnn import keras_h5
+    h5 = str(tmp_path / "weights.hdf5")
+    m_all.save_weights(h5)
+    layers, names = keras_h5.read_keras_weights(h5)
+    assert names["conv1"] == ["conv1/kernel:0", "conv1/bias:0"] and layers["res5a_branch2a"][0].shape == (1, 1, 1024, 512)
+    assert names["bn_conv1"][3] == "bn_conv1/bn_conv1_running_std:0" and len(layers["rpn_out_regress"]) == 2
+    W0 = m_all._s.eng.get_weights()
+    m_rpn.train_on_batch(X, [np.ones((1,) + a[0].shape[1:3] + (24,), np.float32), np.ones((1,) + a[0].shape[1:3] + (96,), np.float32)])
+    Wt = m_all._s.eng.get_weights()
+    assert not np.array_equal(Wt["rpn_conv1"]["kernel"], W0["rpn_conv1"]["kernel"])      # the step really moved the weights
+    m_all.load_weights(h5, by_name=True)                         # restores the saved weights exactly
+    W1 = m_all._s.eng.get_weights()
+    assert all(np.array_equal(W0[n][k], W1[n][k]) for n in W0 for k in W0[n])
+    c = m_rpn3.predict(X)
+    assert all(np.array_equal(u, v) for u, v in zip(a, c))
 
 
 def test_cfg3_predict_tile_2048(models):

@@ -29,13 +29,20 @@ def main():
     keys = sorted((k for k in p1 if "conv_" in k), key=lambda k: -d1[k])
     print("pass 1 (SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY")
     print("        SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE), aggregated over every launch of the kernel template:")
-    print("  GRBM_GUI_ACTIVE is summed over the 8 XCDs (guide: DVFS give-back) -> busy%% = MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs)")
+    print("  MFMA busy %% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz): the share of the chip's matrix-pipe cycles")
+    print("  AT THE PEAK CLOCK the launches kept busy, so busy %% x 157.3 = the fp32 TFLOP/s the MFMAs executed (one v_mfma_f32_32x32x2_f32")
+    print("  = 64 busy cycles = 4096 flop -> 'executed TF/s' = busy cycles x 64 / duration).  Round 1 divided by GRBM_GUI_ACTIVE / 8")
+    print("  instead; that counter reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back) -- every launch")
+    print("  here is 10-50 us -- which made busy %% read ~1.5x too low against the measured flop rate.  It is kept as 'gui-norm'.")
     for k in keys:
         c = p1[k]
         gui = c["GRBM_GUI_ACTIVE"] / 8.0
         wc = max(c["SQ_WAVE_CYCLES"], 1.0)
-        print("  %-44s n=%5d  avg %6.1f us  MFMA busy %5.1f %%  of wave cycles: wait %.2f  issue-stall %.2f  active %.2f   LDS conflict/active %.3f"
-              % (k, n1[k], d1[k] / n1[k], 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(gui * 1024.0, 1.0), c["SQ_WAIT_ANY"] / wc,
+        dur_s = d1[k] * 1e-6
+        busy = c["SQ_VALU_MFMA_BUSY_CYCLES"]
+        print("  %-44s n=%5d  avg %6.1f us  MFMA busy %5.1f %% (executed %6.1f TF/s; gui-norm %5.1f %%)  of wave cycles: wait %.2f  issue-stall %.2f  active %.2f   LDS conflict/active %.3f"
+              % (k, n1[k], d1[k] / n1[k], 100.0 * busy / max(1024.0 * dur_s * 2.4e9, 1.0), busy * 64.0 / max(dur_s, 1e-12) / 1e12,
+                 100.0 * busy / max(gui * 1024.0, 1.0), c["SQ_WAIT_ANY"] / wc,
                  c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)))
     print("pass 2 / 3 (FETCH_SIZE, WRITE_SIZE; KB per dispatch summed over the L2 channels):")
     print("  gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (upper bound for narrow reads); WRITE_SIZE exact")
