@@ -374,8 +374,9 @@ def main():
                 "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}
         if rank == 0 and not cont and hasattr(eng, "_plan_rpn"):
             try:
-                bp0 = eng._plan_base(1, args.height, args.width, 0)
-                roof["layers_3x3"] = layers_3x3_table(eng, bp0, eng._plan_rpn(bp0["fh"], bp0["fw"], bp0["F"]))
+                nb0 = args.per_gpu_batch if getattr(ts, "batched", False) else 1       # the mini-batch runs as one program
+                bp0 = eng._plan_base(nb0, args.height, args.width, 0)
+                roof["layers_3x3"] = layers_3x3_table(eng, bp0, eng._plan_rpn(bp0["fh"], bp0["fw"], bp0["F"], nb0))
             except Exception as e:                       # a secondary table must never cost the bench line
                 roof["layers_3x3_error"] = repr(e)
     coll = collectives_leg(eng, ts, dist, world) if (dist is not None and not cont) else None
@@ -395,6 +396,8 @@ def main():
                                    % (args.width, args.height, args.per_gpu_batch,
                                       "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
                        "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
+                       "mini_batch_form": ("one layer program, images stacked along the GEMM M dimension" if getattr(ts, "batched", False) and args.per_gpu_batch > 1
+                                           else "image by image"),
                        "parallelism": "dp%d" % world,
                        "schedule": ("one lane" if cont or not getattr(ts, "side_prefetch", False) else
                                     "pipelined over HIP streams: %d prefetch lanes (base forward, 3 batches ahead), RPN phase, head phase"

@@ -124,6 +124,7 @@ class FasterRCNNEngine:
 
     NETWORK = "resnet50"
     N_FEATURES = 1024
+    supports_batched = True      # per-GPU mini-batch as one layer program (upload_images / _plan_rpn(nb) / _plan_head(groups))
     feat_len = staticmethod(feat_len)
 
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5, autotune=True):
@@ -450,7 +451,7 @@ class FasterRCNNEngine:
                 out = buf(nb, oh, ow, f3)
                 d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
                 cur, h, w = out, oh, ow
-        plan = dict(ops=ops, x=x, F=cur, fh=h, fw=w, keep=keep)
+        plan = dict(ops=ops, x=x, F=cur, fh=h, fw=w, keep=keep, nb=nb)
         self._plans[key] = plan
         return plan
 
@@ -671,6 +672,30 @@ class FasterRCNNEngine:
         plan["raw_read"].record()
         return plan
 
+    def upload_images(self, imgs, slot=0):
+        """Per-GPU mini-batch as ONE layer program (BASELINE cfg 4: per-GPU batch 2): the nb images (same size) land in one
+        [nb][H][W][4] input tensor, so every base / RPN GEMM runs once with M = nb * H' * W' rows instead of nb times with
+        H' * W' -- at batch 1 the launches are too small to fill 256 CUs, doubling M halves the fixed cost
+        per image.  Same pinned-staging path per image as upload_image."""
+        nb = len(imgs)
+        H, W = imgs[0].shape[:2]
+        plan = self._plan_base(nb, H, W, slot)
+        if "raws" not in plan:
+            plan["raws"] = [torch.empty(H, W, 3, dtype=torch.uint8, device=self.dev) for _ in range(nb)]
+            plan["h_raws"] = [torch.empty(H, W, 3, dtype=torch.uint8).pin_memory() for _ in range(nb)]
+            plan["raw_free"] = torch.cuda.Event()
+            plan["raw_free"].record()
+        plan["raw_free"].synchronize()             # the previous DMAs out of the staging buffers have finished
+        for i, img in enumerate(imgs):
+            if img.shape[:2] != (H, W):
+                raise L.RadnetError("upload_images: images of one mini-batch must share their size")
+            np.copyto(plan["h_raws"][i].numpy(), img)
+            plan["raws"][i].copy_(plan["h_raws"][i], non_blocking=True)
+        plan["raw_free"].record()
+        for i in range(nb):
+            self.ctx.call("radnet_preprocess_bgr", plan["raws"][i], H, W, 4, plan["x"][i])
+        return plan
+
     def upload_preprocessed(self, X):
         """X: (1,H,W,3) fp32 already preprocessed by the caller (Keras-style model.predict input)."""
         _, H, W, _ = X.shape
@@ -684,18 +709,21 @@ class FasterRCNNEngine:
         self._run(plan["ops"])
         return plan["F"]
 
-    def _plan_rpn(self, fh, fw, F):
-        key = ("rpn", fh, fw, F.data_ptr())
+    def _plan_rpn(self, fh, fw, F, nb=1):
+        """nb > 1: the RPN of a per-GPU mini-batch as one program (rows of image i are [i*M, (i+1)*M)); losses and
+        proposals stay per image (rpn_image), the backward GEMMs sum the gradient over the nb images by construction."""
+        key = ("rpn", fh, fw, F.data_ptr(), nb)
         if key in self._plans:
             return self._plans[key]
         dev = self.dev
-        M = fh * fw
-        hbuf = torch.empty(1, fh, fw, 512, dtype=torch.float32, device=dev)
+        M1 = fh * fw
+        M = nb * M1
+        hbuf = torch.empty(nb, fh, fw, 512, dtype=torch.float32, device=dev)
         pred = torch.empty(M, RPN_LD, dtype=torch.float32, device=dev)
         c1, ch = self.convs["rpn_conv1"], self.convs["rpn_heads"]
         wino_keep = []
-        op1, d1 = self._fwd_op(c1, F, 1, fh, fw, hbuf, wino_keep, relu=True)
-        d2, _, _ = self._desc(ch, hbuf, 1, fh, fw, pred, act=2, act_cols=self.A)
+        op1, d1 = self._fwd_op(c1, F, nb, fh, fw, hbuf, wino_keep, relu=True)
+        d2, _, _ = self._desc(ch, hbuf, nb, fh, fw, pred, act=2, act_cols=self.A)
         # backward
         dz = torch.zeros(M, RPN_LD, dtype=torch.float32, device=dev)
         dh = torch.empty(M, 512, dtype=torch.float32, device=dev)
@@ -713,27 +741,52 @@ class FasterRCNNEngine:
             dZ = torch.empty(16, T, c1.cout, dtype=torch.float32, device=dev)
             dU = torch.empty(16, c1.cin, c1.cout, dtype=torch.float32, device=dev)
             wino_keep += [dZ, dU]
-            wg1 = ("wino_wgrad", [dh.data_ptr(), 1, fh, fw, c1.cin, c1.cout, 512, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T,
+            wg1 = ("wino_wgrad", [dh.data_ptr(), nb, fh, fw, c1.cin, c1.cout, 512, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T,
                                   c1.dweight.data_ptr(), c1.ldw, 1])
         else:
             wg1 = ("wgrad", b1)
         bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),
-               ("dgrad", b2), wg1, ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]
+               ("dgrad", b2), wg1, ("colsum", [dh.data_ptr(), M, 512, 512, None, c1.dbias.data_ptr(), 1])]      # M = all nb images
         bwd = self._fuse_bias_grads(bwd)
-        ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M * self.A))
+        ws_bytes = int(self.lib.radnet_proposals_ws_bytes(M1 * self.A))
         # the re-prediction after Adam #1 (train.py:291) sees the same feature map: its input transform is already in V
         refwd = [("wino_reuse", op1[1]) if op1[0] == "wino" else op1, ("conv", d2)]
-        plan = dict(fwd=[op1, ("conv", d2)], refwd=refwd, bwd=bwd, b1=b1, h=hbuf, pred=pred, dz=dz, dh=dh, M=M, fh=fh, fw=fw, wino_keep=wino_keep,
+        plan = dict(fwd=[op1, ("conv", d2)], refwd=refwd, bwd=bwd, b1=b1, h=hbuf, pred=pred, dz=dz, dh=dh, M=M1, nb=nb, fh=fh, fw=fw,
+                    wino_keep=wino_keep,
                     prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
                     R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
                     Rn=torch.zeros(1, dtype=torch.int32, device=dev))
+        if nb > 1:          # per-image views: scores / gradients of image i, its own proposal buffers
+            plan["images"] = [dict(pred=pred[i * M1:(i + 1) * M1], dz=dz[i * M1:(i + 1) * M1], M=M1, fh=fh, fw=fw,
+                                   prop_ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
+                                   R=torch.zeros(1024, 4, dtype=torch.int64, device=dev), Rp=torch.zeros(1024, dtype=torch.float32, device=dev),
+                                   Rn=torch.zeros(1, dtype=torch.int32, device=dev)) for i in range(nb)]
         self._plans[key] = plan
         return plan
 
     def rpn_forward(self, bplan):
-        rp = self._plan_rpn(bplan["fh"], bplan["fw"], bplan["F"])
+        rp = self._plan_rpn(bplan["fh"], bplan["fw"], bplan["F"], bplan.get("nb", 1))
         self._run(rp["fwd"])
         return rp
+
+    @staticmethod
+    def rpn_image(rp, i):
+        """View of image i of a (possibly batched) RPN plan: what proposals() and the capture hooks read."""
+        return rp["images"][i] if rp.get("nb", 1) > 1 else rp
+
+    def rpn_loss_image(self, rp, i, y_cls, y_regr, loss_out=None):
+        """Losses of ONE image of a batched RPN plan (every image is an independent reference step with its own
+        normalisers, losses.py:16-66) + its rows of the pre-activation gradient; rpn_backward_batched() then runs the
+        backward GEMMs once over all images.  y_cls None: the image was dropped by the labeller -- zero gradient rows."""
+        v = self.rpn_image(rp, i)
+        if y_cls is None:
+            self.ctx.call("radnet_fill_zero", v["dz"], C.c_uint64(v["M"] * RPN_LD * 4))
+            return
+        self.ctx.call("radnet_rpn_loss", v["pred"], RPN_LD, y_cls, y_regr, v["M"], self.A, self.bce_mode, v["dz"], RPN_LD,
+                      self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
+
+    def rpn_backward_batched(self, rp):
+        self._run(rp["bwd"])
 
     def rpn_backward(self, rp, y_cls, y_regr, loss_out=None):
         """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
@@ -763,12 +816,16 @@ class FasterRCNNEngine:
         return rp["R"], rp["Rn"]
 
     # ------------------------------------------------------------------------------------------ classifier head
-    def _plan_head(self, R, fh, fw, F, training=True):
+    def _plan_head(self, R, fh, fw, F, training=True, groups=1):
         """training=False (DetectorModel.predict / RADNet's tile path): forward buffers only -- the backward program's
-        gradient buffers (~1.4 GB at R = 300) are not allocated for a plan that never differentiates."""
-        key = ("head" if training else "head_inf", R, fh, fw, F.data_ptr())
+        gradient buffers (~1.4 GB at R = 300) are not allocated for a plan that never differentiates.
+        groups > 1 (per-GPU mini-batch): F is [groups][fh][fw][C] and the R RoIs are groups x R/groups, group g cropped from
+        feature map g; stage 5 then runs ONCE over all R RoIs (GEMM M = R * 49), losses stay per image."""
+        key = ("head" if training else "head_inf", R, fh, fw, F.data_ptr(), groups)
         if key in self._plans:
             return self._plans[key]
+        if R % groups:
+            raise L.RadnetError("head plan: %d RoIs do not split into %d groups" % (R, groups))
         dev = self.dev
         keep = []
 
@@ -803,7 +860,7 @@ class FasterRCNNEngine:
         y1, y2 = buf(R, self.nc), buf(R, 2 * self.nreg)
         if not training:
             plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls, pregr=pregr,
-                        F=F, fh=fh, fw=fw, keep=keep)
+                        F=F, fh=fh, fw=fw, keep=keep, groups=groups)
             self._plans[key] = plan
             return plan
         dz = buf(R, self.nc + self.nreg)
@@ -858,7 +915,7 @@ class FasterRCNNEngine:
         if [sl for _, sl in bwd_parts] != self.head_exchange_slices():
             raise RuntimeError("head backward parts and head_exchange_slices() disagree")
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
-                    pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep)
+                    pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep, groups=groups)
         self._plans[key] = plan
         return plan
 
@@ -886,7 +943,13 @@ class FasterRCNNEngine:
 
     def head_forward(self, hp, training=False):
         """classifier_layer forward (`training` only matters for the VGG16 head's Dropout)."""
-        self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
+        G = hp.get("groups", 1)
+        if G == 1:
+            self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
+        else:
+            rg = hp["R"] // G
+            for g in range(G):                  # RoIs of image g crop feature map g
+                self.ctx.call("radnet_roi_resize_fwd", hp["F"][g], hp["fh"], hp["fw"], 1024, hp["rois"][g * rg:], rg, 14, hp["pooled"][g * rg:])
         self._run(hp["fwd"])
         self.ctx.call("radnet_avgpool_fwd", hp["y5"], hp["R"], hp["hw"], 2048, hp["feat"])
         self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
@@ -898,8 +961,21 @@ class FasterRCNNEngine:
         the flat gradient arena that block has just completed -- the data-parallel trainer starts that slice's all-reduce
         while the earlier blocks are still being differentiated; the biases and the dense heads (the arena's tail from
         head_bias_off) are complete when the call returns."""
-        self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
-                      self.det_losses if loss_out is None else loss_out)
+        G = hp.get("groups", 1)
+        if G == 1:
+            self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
+                          self.det_losses if loss_out is None else loss_out)
+        else:
+            # every image is its own reference step (losses.py:69-95 normalise per call): loss + gradient rows per group;
+            # loss_out is then a list with one slot per group, None = that image takes no classifier step (zero rows)
+            rg = hp["R"] // G
+            for g in range(G):
+                lo = loss_out[g] if loss_out is not None else self.det_losses
+                if lo is None:
+                    self.ctx.call("radnet_fill_zero", hp["dz"][g * rg:], C.c_uint64(rg * (self.nc + self.nreg) * 4))
+                    continue
+                self.ctx.call("radnet_det_loss", hp["pcls"][g * rg:], hp["pregr"][g * rg:], hp["y1"][g * rg:], hp["y2"][g * rg:], rg, self.nc,
+                              self.nreg, hp["dz"][g * rg:], lo)
         self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
                       self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
         self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
@@ -1005,11 +1081,19 @@ class FasterRCNNEngine:
         n = int(P["h_n"][0])
         return P, P["h_cls"].numpy()[:max(n, 0)], n
 
-    def pack_roi_batch(self, P, sel, hp):
+    def pack_roi_batch(self, P, sel, hp, group=0):
+        """Selected RoIs + targets of one image into the head plan (rows of `group` in a per-GPU mini-batch plan)."""
         k = len(sel)
+        o = group * (hp["R"] // hp.get("groups", 1))
         P["h_sel"][:k] = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32))
         P["sel"][:k].copy_(P["h_sel"][:k], non_blocking=True)
-        self.ctx.call("radnet_roi_batch_pack", P["sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"], hp["y1"], hp["y2"])
+        self.ctx.call("radnet_roi_batch_pack", P["sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"][o:], hp["y1"][o:], hp["y2"][o:])
+
+    def idle_roi_group(self, hp, group):
+        """An image of the mini-batch that takes no classifier step (no RoI kept / dropped by the labeller): its rows still
+        pass through the stage-5 GEMMs, on a harmless 1x1 RoI; head_backward zeroes their gradient."""
+        rg = hp["R"] // hp["groups"]
+        hp["rois"][group * rg:(group + 1) * rg].copy_(torch.tensor([0.0, 0.0, 1.0, 1.0], device=self.dev).expand(rg, 4))
 
 
 def _uniform_table_probs(chan_of_item, neg_chans, n_total):

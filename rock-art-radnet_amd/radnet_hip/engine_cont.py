@@ -21,6 +21,7 @@ from .engine import RES_STAGES, Arena, FasterRCNNEngine
 
 
 class ContEngine(FasterRCNNEngine):
+    supports_batched = False     # cont_train.py's step runs one image at a time (both optimizers move the shared stages)
 
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=2e-5, autotune=True):
         super().__init__(C_cfg, device_index, n_classes, bce_mode, lr, autotune)
@@ -208,7 +209,9 @@ class ContEngine(FasterRCNNEngine):
         self._run(plan["bwd34"])
 
     # ------------------------------------------------------------------------------------------ RPN: continue into dF
-    def _plan_rpn(self, fh, fw, F):
+    def _plan_rpn(self, fh, fw, F, nb=1):
+        if nb != 1:
+            raise L.RadnetError("ContEngine: the cont_train.py step runs one image at a time")
         rp = super()._plan_rpn(fh, fw, F)
         if "cont" not in rp:
             base = self._base_of_F[F.data_ptr()]

@@ -86,6 +86,9 @@ class TrainStep:
         self._slots = 0                  # batches started: buffer set = count % NBUF
         # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
         self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "lane")
+        # per-GPU mini-batch (BASELINE cfg 4) as ONE layer program: base / RPN / stage-5 GEMMs run once with the images
+        # stacked along M (RADNET_BATCHED=0: image by image, the round-1 path)
+        self.batched = os.environ.get("RADNET_BATCHED", "1") == "1" and getattr(eng, "supports_batched", False)
         self.skipped_head_steps = 0
         self.dropped_images = 0     # images whose anchor labelling raised (reference: sample skipped, utils.py:461-465)
         self.on_drop = None         # optional callback(sample, exception); default: one line on stderr, like the reference's print
@@ -142,15 +145,21 @@ class TrainStep:
         for i, s in enumerate(batch):
             H, W = s["img"].shape[:2]
             tp.append(eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=slot * nloc + i))
-        for i, s in enumerate(batch):
-            bp = eng.upload_image(s["img"], slot=slot * nloc + i)
+        stacked = self.batched and nloc > 1 and len({s["img"].shape[:2] for s in batch}) == 1
+        if stacked:
+            bp = eng.upload_images([s["img"] for s in batch], slot=slot)
             eng.base_forward(bp)
-            plans.append(bp)
-        return dict(batch=batch, tp=tp, plans=plans, rps=None, slot=slot)
+            plans = [bp]
+        else:
+            for i, s in enumerate(batch):
+                bp = eng.upload_image(s["img"], slot=slot * nloc + i)
+                eng.base_forward(bp)
+                plans.append(bp)
+        return dict(batch=batch, tp=tp, plans=plans, rps=None, slot=slot, stacked=stacked)
 
     def _launch_b(self, st):
         """RPN forward of every image of a batch whose base forward is enqueued: reads the RPN weights."""
-        st["rps"] = [self.eng.rpn_forward(bp) for bp in st["plans"]]
+        st["rps"] = [self.eng.rpn_forward(bp) for bp in st["plans"]]      # stacked: one program over all images
         return st
 
     def _launch_ab(self, batch, slot):
@@ -171,6 +180,7 @@ class TrainStep:
         # this batch before anything of it touches a gradient; the rest of the batch, and the head phase of the batch before
         # it (pipelined mode), go on.
         dead = st["dead"] = [False] * nloc
+        stacked = st.get("stacked", False)
         n_live = 0
         for i in range(nloc):
             try:
@@ -179,11 +189,19 @@ class TrainStep:
                 dead[i] = True
                 self.dropped_images += 1
                 self._report_drop(batch[i], e)
+                if stacked:
+                    eng.rpn_loss_image(rps[0], i, None, None)          # zero gradient rows for the dropped image
                 continue
             mark("A: label maps on host, subsampled, packed")
-            eng.set_accumulate(rps[i]["bwd"], n_live > 0, prezeroed=True)
-            eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[slot][i])
+            if stacked:
+                eng.rpn_loss_image(rps[0], i, ycls, yregr, self._rpn_l[slot][i])
+            else:
+                eng.set_accumulate(rps[i]["bwd"], n_live > 0, prezeroed=True)
+                eng.rpn_backward(rps[i], ycls, yregr, self._rpn_l[slot][i])
             n_live += 1
+        if stacked and n_live > 0:
+            eng.set_accumulate(rps[0]["bwd"], False, prezeroed=True)
+            eng.rpn_backward_batched(rps[0])                           # ONE backward over all images' rows: the summed gradient
         st["roi"] = [None] * nloc
         if n_live == 0 and self.world == 1 and not FORCE_COLLECTIVES:
             st["adam1"] = eng.mark() if hasattr(eng, "mark") else None
@@ -194,12 +212,15 @@ class TrainStep:
         eng.adam(eng.rpn_arena, grad_scale=1.0 / ntot)
         st["adam1"] = eng.mark() if hasattr(eng, "mark") else None
         mark("C: rpn backward + adam enqueued")
-        for i, bp in enumerate(plans):
+        if stacked:
+            eng._run(rps[0].get("refwd", rps[0]["fwd"]))
+        for i in range(nloc):
             if dead[i]:
                 continue
             s = batch[i]
-            eng._run(rps[i].get("refwd", rps[i]["fwd"]))      # same feature map as the first pass: no second input transform
-            R, Rn = eng.proposals(rps[i], overlap_thresh=0.7, max_boxes=300)
+            if not stacked:
+                eng._run(rps[i].get("refwd", rps[i]["fwd"]))      # same feature map as the first pass: no second input transform
+            R, Rn = eng.proposals(eng.rpn_image(rps[0], i) if stacked else rps[i], overlap_thresh=0.7, max_boxes=300)
             rw, rh = new_img_size(s["width"], s["height"], C.img_size)       # rpn.py:189 recomputes it from the config
             st["roi"][i] = (R, eng.roi_targets_launch(R, Rn, self._gt(s), s["width"], s["height"], rw, rh, slot=slot * nloc + i))
         mark("D: rpn re-predict + proposals + roi targets enqueued")
@@ -315,7 +336,8 @@ class TrainStep:
             picks.append((P, kept[np.asarray(sel_k, dtype=np.int64)]))
             mark("D: samples selected")
             if self.capture is not None:
-                self.capture.append(dict(pred=st["rps"][i]["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(),
+                view = eng.rpn_image(st["rps"][0], i) if st.get("stacked") else st["rps"][i]
+                self.capture.append(dict(pred=view["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(),
                                          keep=(cls >= 0).copy(), cls=cls.copy(), sel_kept=list(sel_k)))
         # ---- pipelined: the next batch's RPN phase goes first -- the host sync of the NEXT call waits for it
         if pipelined:
@@ -336,7 +358,25 @@ class TrainStep:
             works.append(allreduce_grad_arena_start(eng.head_arena.g[lo:hi], self.world, self.group_head))
 
         with head_lane():      # what it reads from the other lanes (feature map, RoI labels) is complete: the host waited
-            for i, bp in enumerate(st["plans"]):
+            if st.get("stacked") and live:
+                # per-GPU mini-batch: all images' RoIs through stage 5 in ONE pass (GEMM M = nloc * n_rois * 49); losses per
+                # image, an image without a classifier step contributes zero gradient rows
+                bp = st["plans"][0]
+                hp = eng._plan_head(nloc * C.n_rois, bp["fh"], bp["fw"], bp["F"], groups=nloc)
+                slots = []
+                for i in range(nloc):
+                    if picks[i] is None:
+                        eng.idle_roi_group(hp, i)
+                        slots.append(None)
+                    else:
+                        eng.pack_roi_batch(picks[i][0], picks[i][1], hp, group=i)
+                        slots.append(self._det_l[slot][n_head])
+                        n_head += 1
+                self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
+                eng.head_forward(hp, training=True)
+                eng.set_accumulate(hp["bwd"], False, prezeroed=True)
+                eng.head_backward(hp, accumulate=True, loss_out=slots, on_part=exchange if bucketed else None)
+            for i, bp in enumerate(st["plans"] if not st.get("stacked") else []):
                 if picks[i] is None:
                     continue
                 hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])

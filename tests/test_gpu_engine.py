@@ -202,10 +202,13 @@ def test_full_train_step_vs_oracle():
             assert np.abs(d_gpu).max() <= 5e-5 * 1.0001
 
 
-def test_cfg4_two_images_per_step_vs_oracle():
+@pytest.mark.parametrize("stacked", [True, False], ids=["one_program_M_doubled", "image_by_image"])
+def test_cfg4_two_images_per_step_vs_oracle(stacked):
     """BASELINE config 4 semantics on one GPU: two images per step, each an independent reference iteration on the same
     weights, both optimizers applied once with the mean gradient (what the data-parallel ranks compute together).
-    Losses per image, RNG consumption and the first Adam step's weight deltas against the oracle's step_batch."""
+    Losses per image, RNG consumption and the first Adam step's weight deltas against the oracle's step_batch.
+    stacked: the mini-batch as ONE layer program (base / RPN / stage-5 GEMMs with the images stacked along M, what
+    `bench.py --per-gpu-batch 2` runs) -- or the images one after the other through nb = 1 programs."""
     import copy
     from faster_rcnn.config import Config
     from oracle import dense, step as ostep
@@ -223,12 +226,22 @@ def test_cfg4_two_images_per_step_vs_oracle():
         batch.append(dict(img=synth.synthetic_panel(10 + i, 300, 500), bboxes=meta["bboxes"], width=1000, height=600))
     np.random.seed(64)
     ts = TrainStep(eng)
+    assert ts.batched                      # the default for the ResNet50 engine
+    ts.batched = stacked
     ts.capture = []
     ts.step(batch)
     got = ts.losses()
     rng_gpu = np.random.randint(0, 2 ** 31 - 1)
     w_after = eng.get_weights()
     assert got["n_head"] == 2 and len(ts.capture) == 2
+    # proposals of each image: bit-exact against the oracle on the device's own (post-update) scores of THAT image
+    from oracle import glue
+    fh, fw = glue.resnet50_feat_len(300), glue.resnet50_feat_len(500)
+    for c in ts.capture:
+        assert c["pred"].shape == (fh * fw, 64)
+        Rref = glue.rpn_to_roi(c["pred"][:, :12].reshape(1, fh, fw, 12), c["pred"][:, 12:60].reshape(1, fh, fw, 48), C, True, 300, 0.7)
+        assert np.array_equal(c["R"], Rref)
+    assert not np.array_equal(ts.capture[0]["pred"], ts.capture[1]["pred"])
 
     np.random.seed(64)
     ot = ostep.OracleTrainer(C, copy.deepcopy(P))

@@ -227,3 +227,53 @@ def test_cfg5_vgg16_base_and_rpn_1000x600_vs_oracle():
     n = int(Rn.cpu()[0])
     Rref = glue.rpn_to_roi(pred[:, :9].reshape(1, 37, 62, 9), pred[:, 9:45].reshape(1, 37, 62, 36), C, True, 300, 0.7)
     assert n == len(Rref) and np.array_equal(R.cpu().numpy()[:n], Rref)
+
+
+def test_cfg4_per_gpu_batch_2_at_1000x600_one_program_vs_oracle():
+    """BASELINE cfg 4 on one GPU at full size: two 1000x600 panels per step as ONE layer program (every base / RPN GEMM with
+    M doubled, 40 RoIs through stage 5 in one pass) against the oracle's step_batch: per-image proposals bit-exact on the
+    device's tensors, sample selection and RNG consumption exact, mean losses, first Adam step of both optimizers."""
+    from faster_rcnn.config import Config
+    from oracle import dense, glue, step as ostep
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    P = dense.init_params(seed=3)
+    eng = FasterRCNNEngine(C)
+    eng.set_weights(P)
+    batch = []
+    for i in range(2):                      # SURVEY.md 8d cfg 4: seeds 100 + rank*2 + i (rank 0)
+        meta = synth.synthetic_gt(100 + i, n=8, src_w=2000, src_h=1200)
+        batch.append(dict(img=synth.synthetic_panel(100 + i, 600, 1000), bboxes=meta["bboxes"], width=2000, height=1200))
+    np.random.seed(64)
+    ts = TrainStep(eng)
+    assert ts.batched
+    ts.capture = []
+    ts.step(batch)
+    got = ts.losses()
+    rng_gpu = int(np.random.randint(0, 2 ** 31 - 1))
+    w_after = eng.get_weights()
+    assert len(ts.capture) == got["n_head"] and got["n_head"] >= 1
+    for c in ts.capture:
+        Rref = glue.rpn_to_roi(c["pred"][:, :12].reshape(1, 38, 63, 12), c["pred"][:, 12:60].reshape(1, 38, 63, 48), C, True, 300, 0.7)
+        assert np.array_equal(c["R"], Rref)
+    if got["n_head"] != 2:
+        pytest.skip("one of the two synthetic panels kept no RoI: the per-image comparison below needs both")
+    np.random.seed(64)
+    ot = ostep.OracleTrainer(C, copy.deepcopy(P))
+    det = []
+    ref = ostep.step_batch(ot, batch, details=det, override_R=[c["R"] for c in ts.capture])
+    assert int(np.random.randint(0, 2 ** 31 - 1)) == rng_gpu
+    for c, d in zip(ts.capture, det):
+        assert c["sel_kept"] == d["sel"]
+    r = np.array(ref, dtype=np.float64)
+    assert abs(got["rpn_cls"] - r[:, 0].mean()) < 1e-3 * abs(r[:, 0].mean())
+    assert abs(got["rpn_regr"] - r[:, 1].mean()) < 1e-3 * abs(r[:, 1].mean()) + 1e-6
+    assert abs(got["det_cls"] - r[:, 2].mean()) < 2e-3 * abs(r[:, 2].mean())
+    assert abs(got["det_regr"] - r[:, 3].mean()) < 2e-3 * abs(r[:, 3].mean()) + 1e-5
+    for name in ("rpn_conv1", "rpn_out_class", "rpn_out_regress", "res5a_branch2a", "res5b_branch2b", "res5c_branch2c", "dense_regress_7"):
+        for k in ("kernel", "bias"):
+            d_ref, d_gpu = ot.P[name][k] - P[name][k], w_after[name][k] - P[name][k]
+            big = np.abs(d_ref) > 0.9 * 5e-5                               # first Adam step: |delta| ~ lr where the gradient is not tiny
+            assert big.sum() > 0 and np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
