@@ -113,7 +113,7 @@ def layers_3x3_table(eng, bp, rp):
             continue
         for name in wanted:
             c = eng.convs[name]
-            if p[7] == c.wino_u.data_ptr():
+            if c.wino_u is not None and p[7] == c.wino_u.data_ptr():
                 found[name] = p
     for name, label in wanted.items():
         if name not in found:
@@ -122,12 +122,13 @@ def layers_3x3_table(eng, bp, rp):
         x, nb, hh, ww, cin, n, V, U, M, T, scale, shift, act, y, ldy = found[name]
         h = eng.ctx.h
         t_in = _time_us(lambda: lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V))
-        t_g = _time_us(lambda: lib.radnet_gemm_batched(h, V, U, M, 16, T, n, cin))
+        gemm = lib.radnet_gemm_batched
+        t_g = _time_us(lambda: gemm(h, V, U, M, 16, T, n, cin))
         t_out = _time_us(lambda: lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy))
 
         def layer():
             lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V)
-            lib.radnet_gemm_batched(h, V, U, M, 16, T, n, cin)
+            gemm(h, V, U, M, 16, T, n, cin)
             lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
         t_layer = _time_us(layer)
         d, _, _ = eng._desc(c, _Ptr(x), nb, hh, ww, _Ptr(y), relu=bool(act))
@@ -288,13 +289,14 @@ def main():
     # Priming (the "compile" of this framework, outside W and K): every GEMM shape is measured once, every layer program of
     # every buffer set runs once eagerly and is then recorded into its hipGraph -- 2 uses per buffer set.  Without it a short
     # warm-up (W < 13) would leave graph captures, each with a device synchronisation, inside the timed region.
+    LOOK = getattr(ts, "LOOKAHEAD", 3)        # announced batches the step uses (a prefetching loader knows them)
     n_prime = 2 * getattr(ts, "NBUF", 1) + 2
     for k in range(n_prime):
-        ts.step(batch, upcoming=[batch] * min(3, n_prime - 1 - k))
+        ts.step(batch, upcoming=[batch] * min(LOOK, n_prime - 1 - k))
     ts.flush()
     barrier()
     for k in range(args.warmup):      # the pipeline drains at the end of the warm-up: nothing of the timed steps is enqueued early
-        ts.step(batch, upcoming=[batch] * min(3, args.warmup - 1 - k))
+        ts.step(batch, upcoming=[batch] * min(LOOK, args.warmup - 1 - k))
     ts.flush()
     barrier()
     # Everything long-lived exists now (plans, descriptors, graphs): collect once and move it to the permanent generation,
@@ -309,7 +311,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # the input pipeline knows the next batch: its label / base-forward phases are enqueued across the host sync
-        ts.step(batch, upcoming=[batch] * min(3, args.steps - 1 - k))
+        ts.step(batch, upcoming=[batch] * min(LOOK, args.steps - 1 - k))
     ts.flush()                       # multi-GPU: the last step's deferred head update belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
@@ -400,8 +402,9 @@ def main():
                                            else "image by image"),
                        "parallelism": "dp%d" % world,
                        "schedule": ("one lane" if cont or not getattr(ts, "side_prefetch", False) else
-                                    "pipelined over HIP streams: %d prefetch lanes (base forward, 3 batches ahead), RPN phase, head phase"
-                                    % getattr(eng, "n_side_lanes", 1)),
+                                    "pipelined over HIP streams: %d prefetch lanes (frozen base forward, %d batches ahead%s), RPN phase, head phase"
+                                    % (getattr(eng, "n_side_lanes", 1), LOOK,
+                                       ", two consecutive batches' base forwards as one nb=2 program" if getattr(ts, "stack_base", False) and args.per_gpu_batch == 1 else "")),
                        "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
                        "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},
             "losses": losses,

@@ -55,8 +55,9 @@ def allreduce_grad_arena_start(flat, world, group=None):
 
 
 class TrainStep:
-    NBUF = 6        # buffer sets in rotation: this batch, up to three announced ones, whose head phase may still run; even,
-                    # so that the sets alternate between the two prefetch lanes
+    NBUF = 8        # buffer sets in rotation: this batch, up to four announced ones, whose head phase may still run; even,
+                    # so that the sets alternate between the two prefetch lanes (and pairs of sets stay pairs)
+    LOOKAHEAD = 4   # announced batches used (step(upcoming=[...]))
 
     def __init__(self, eng, dist_group=None, world_size=1, defer_head_update=None):
         """defer_head_update (default: on when world_size > 1): the all-reduce of the head gradients (60 MB, the larger
@@ -89,6 +90,16 @@ class TrainStep:
         # per-GPU mini-batch (BASELINE cfg 4) as ONE layer program: base / RPN / stage-5 GEMMs run once with the images
         # stacked along M (RADNET_BATCHED=0: image by image, the round-1 path)
         self.batched = os.environ.get("RADNET_BATCHED", "1") == "1" and getattr(eng, "supports_batched", False)
+        # Pipelined mode, one image per batch: the FROZEN base forward of two consecutive announced batches runs as one
+        # nb = 2 program (the base does not depend on anything the steps in between update), so its GEMMs see M doubled --
+        # the same lever as the per-GPU mini-batch, applied across steps.  The feature maps are the same function of the same
+        # weights; only the GEMM partitioning (and with it fp32 summation order) differs from the nb = 1 program.
+        # Measured on MI355X (bench.py, 300 steps): 479.9 images/s with it, 481.7 without -- the pipelined step is bound by the
+        # aggregate rate at which the chip retires GEMM work with four lanes resident, and there a launch with M doubled is
+        # no faster per image (the per-launch overheads it removes were already hidden by the other lanes).  Hence OFF by
+        # default (every announced batch gets its own nb = 1 base forward: bit-identical to back-to-back steps);
+        # RADNET_STACK_BASE=1 switches it on.
+        self.stack_base = os.environ.get("RADNET_STACK_BASE", "0") == "1" and getattr(eng, "supports_batched", False)
         self.skipped_head_steps = 0
         self.dropped_images = 0     # images whose anchor labelling raised (reference: sample skipped, utils.py:461-465)
         self.on_drop = None         # optional callback(sample, exception); default: one line on stderr, like the reference's print
@@ -164,6 +175,22 @@ class TrainStep:
 
     def _launch_ab(self, batch, slot):
         return self._launch_b(self._launch_a(batch, slot))
+
+    def _launch_pair(self, batch_a, batch_b, slot_a, slot_b):
+        """Phase A + frozen base forward of TWO announced one-image batches as one nb = 2 program (buffer set slot_a).
+        Returns their two states; each sees its own feature map through a one-image view of the stacked plan."""
+        eng = self.eng
+        sts = []
+        for batch, slot in ((batch_a, slot_a), (batch_b, slot_b)):
+            s = batch[0]
+            H, W = s["img"].shape[:2]
+            tp = [eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=slot)]
+            sts.append(dict(batch=batch, tp=tp, plans=None, rps=None, slot=slot, stacked=False))
+        bp = eng.upload_images([batch_a[0]["img"], batch_b[0]["img"]], slot=slot_a)
+        eng.base_forward(bp)
+        for i, st in enumerate(sts):
+            st["plans"] = [dict(F=bp["F"][i:i + 1], fh=bp["fh"], fw=bp["fw"], nb=1, x=bp["x"][i:i + 1], pair=bp)]
+        return sts
 
     def _rpn_phase(self, st, ntot, mark):
         """Phases A (host half) + C + the device part of D for a batch whose forward passes are enqueued: label maps
@@ -265,7 +292,7 @@ class TrainStep:
         mark("start")
         after = getattr(eng, "after", lambda ev: None)
         ahead = list(upcoming) if upcoming is not None else [b for b in (next_batch, after_next) if b is not None]
-        ahead = ahead[:3]                              # lookahead; NBUF - 3 further sets cover head phases still in flight
+        ahead = ahead[:self.LOOKAHEAD]                 # lookahead; the further sets cover head phases still in flight
         pipelined = self.side_prefetch and bool(ahead) and not eng.ctx.timing_on
         # lane mode: from the first pipelined call until flush().  Base forwards and head phases then stay on their lanes
         # (contexts, recorded graphs) also in the calls that announce nothing -- the first and the last step of a run
@@ -298,14 +325,35 @@ class TrainStep:
                     q.pop()
                 break
         if pipelined:
-            for j in range(len(q), len(ahead)):        # prefetch queue: labelling kernels, upload, frozen base forward
+            j = len(q)
+            # more batches will be announced later only if the caller filled the lookahead window: a lone pending batch then
+            # waits one call for its partner (it is not needed before the call after next)
+            more_coming = len(ahead) >= self.LOOKAHEAD
+            while j < len(ahead):                      # prefetch queue: labelling kernels, upload, frozen base forward
+                pairable = (self.stack_base and nloc == 1 and j + 1 < len(ahead) and len(ahead[j]) == 1 and len(ahead[j + 1]) == 1
+                            and ahead[j][0]["img"].shape == ahead[j + 1][0]["img"].shape)
+                if self.stack_base and nloc == 1 and not pairable and j + 1 >= len(ahead) and more_coming and j >= 2:
+                    break                              # lone newcomer at the far end of the window: pair it up next call
                 slot = self._next_slot()
-                k = slot % getattr(eng, "n_side_lanes", 1)   # consecutive batches alternate lanes; a buffer set keeps its lane
-                with eng.lane("side%d" % k if k else "side"):   # (and with it its context: one graph per program)
+                # consecutive batches (pairs) alternate lanes; a buffer set keeps its lane (and with it its context: one graph
+                # per program)
+                k = ((slot // 2) if pairable else slot) % getattr(eng, "n_side_lanes", 1)
+                with eng.lane("side%d" % k if k else "side"):
                     after(self._head_done.get(slot))   # the head phase that last read this buffer set's feature map
-                    nb = self._launch_a(ahead[j], slot)
-                    nb["done"] = eng.mark()
-                    q.append(nb)
+                    if pairable:
+                        slot_b = self._next_slot()
+                        after(self._head_done.get(slot_b))
+                        pair = self._launch_pair(ahead[j], ahead[j + 1], slot, slot_b)
+                        ev = eng.mark()
+                        for nb in pair:
+                            nb["done"] = ev
+                            q.append(nb)
+                        j += 2
+                    else:
+                        nb = self._launch_a(ahead[j], slot)
+                        nb["done"] = eng.mark()
+                        q.append(nb)
+                        j += 1
         elif not lanes:
             after(self._head_last)                     # the head phase below runs on the main lane
             if ahead and not q:

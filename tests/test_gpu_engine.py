@@ -263,8 +263,8 @@ def test_cfg4_two_images_per_step_vs_oracle(stacked):
             assert np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
 
 
-@pytest.mark.parametrize("n_steps,lookahead", [(3, 1), (7, 3)])
-def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead):
+@pytest.mark.parametrize("n_steps,lookahead,stack", [(3, 1, False), (7, 3, False), (9, 4, False), (9, 4, True)])
+def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead, stack):
     """The pipelined step (TrainStep.step(batch, upcoming=[...]): prefetch lanes for the announced batches' base forward, the
     next batch's RPN phase ahead of this batch's head phase, head phase on its own lane -- what bench.py runs) against
     back-to-back steps on one lane.  Same arithmetic, same order of NumPy RNG draws: losses, weights and RNG consumption
@@ -290,6 +290,7 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead):
         eng.set_weights(P)
         np.random.seed(64)
         ts = TrainStep(eng)
+        ts.stack_base = stack              # False: every batch its own nb = 1 base forward -> the schedules are bit-comparable
         losses = []
         for k, b in enumerate(batches):
             ts.step(b, upcoming=batches[k + 1:k + 1 + lookahead] if prefetch else None)
@@ -301,6 +302,16 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead):
             tune = tempfile.mktemp(suffix=".txt")
             eng.save_tuning(tune)
     (l0, w0, r0), (l1, w1, r1) = results
+    if stack:
+        # two announced batches' frozen base forwards ran as ONE nb = 2 program: same function of the same weights, other GEMM
+        # partitioning -> feature maps agree to fp32 rounding, not bit for bit; a near-tied proposal may then be ordered
+        # differently, so the comparison is the one made against the oracle: RPN losses to 1e-3 (every step), RNG consumption
+        # and detector losses only while the two runs still selected the same RoIs
+        for a, b in zip(l0, l1):
+            assert abs(a["rpn_cls"] - b["rpn_cls"]) <= 1e-3 * abs(a["rpn_cls"]) and abs(a["rpn_regr"] - b["rpn_regr"]) <= 1e-3 * abs(a["rpn_regr"]) + 1e-6
+            assert a["n_head"] == b["n_head"] == 1
+        assert abs(l0[0]["det_cls"] - l1[0]["det_cls"]) <= 2e-3 * abs(l0[0]["det_cls"])
+        return
     assert r0 == r1                                   # identical consumption of the global NumPy stream
     for a, b in zip(l0, l1):
         assert a["n_head"] == b["n_head"] == 1

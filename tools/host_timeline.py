@@ -33,8 +33,9 @@ def main():
     ts = TrainStep(eng, defer_head_update=True if nccl1 else None)
     batch = bench.make_batch(0, 1, 600, 1000)
     pipelined = os.environ.get("RADNET_TIMELINE_SERIAL", "0") != "1"       # as bench.py runs it: next batch announced
-    for _ in range(8):
-        ts.step(batch, upcoming=[batch] * 3 if pipelined else None)
+    look = getattr(ts, "LOOKAHEAD", 3)
+    for _ in range(2 * getattr(ts, "NBUF", 6) + 6):          # priming as bench.py: every shape tuned, every program recorded
+        ts.step(batch, upcoming=[batch] * look if pipelined else None)
     torch.cuda.synchronize()
     acc = collections.OrderedDict()
     # split the label-map phase: time inside the host subsampling itself
@@ -61,7 +62,7 @@ def main():
     t_all = time.perf_counter()
     for _ in range(steps):
         ts.host_marks = []
-        ts.step(batch, upcoming=[batch] * 3 if pipelined else None)
+        ts.step(batch, upcoming=[batch] * look if pipelined else None)
         m = ts.host_marks
         for (l0, t0), (l1, t1) in zip(m[:-1], m[1:]):
             acc[l1] = acc.get(l1, 0.0) + (t1 - t0)
