@@ -342,7 +342,6 @@ def main():
         torch.cuda.synchronize()
         eng.ctx.timing(True)
         eng.ctx.timing_reset()
-        eng.wino_timing[:] = [0.0, 0.0, 0]
         for _ in range(args.roofline_steps):
             ts.step(batch)
         ts.flush()                    # data-parallel: the last deferred head update must not be left pending
@@ -358,7 +357,7 @@ def main():
         eng.ctx.timing(False)
         # 3x3 layers run as Winograd F(2x2,3x3) (input transform + 16 batched GEMMs on the same kernel + output transform):
         # timed per LAYER, credited the layer's algorithmic 2*M*N*9C flops, not the 2.25x fewer it executes
-        wms, wfl, wn = eng.wino_timing
+        wms, wn, wfl = eng.ctx.timing_read(3)          # Winograd layers of the programs: timed per layer inside radnet_program_run
         if wn:
             per["conv3x3_winograd_layers"] = {"launches_per_step": wn / args.roofline_steps / args.per_gpu_batch, "avg_us": 1e3 * wms / wn,
                                               "tflops": wfl / max(wms, 1e-9) / 1e9}

@@ -65,7 +65,8 @@ int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);
 int radnet_force_waves(radnet_ctx* ctx, int waves);
 /* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
  * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
- * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd,1 dgrad,2 wgrad). */
+ * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd, 1 dgrad, 2 wgrad, 3 Winograd 3x3 LAYERS
+ * of a program: transforms + 16 GEMMs timed as one unit and credited the layer's algorithmic 2*M*N*9C flops). */
 int radnet_timing_enable(radnet_ctx* ctx, int enable);
 int radnet_timing_read(radnet_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops);
 int radnet_timing_reset(radnet_ctx* ctx);
@@ -259,6 +260,122 @@ int radnet_scatter_strided(radnet_ctx* ctx, const float* src, int32_t nb, int32_
                            int32_t h, int32_t w, const float* mask, float* dst);
 /* g[i] = act[i] > 0 ? g[i] : 0 -- ReLU backward where it cannot ride a GEMM epilogue (VGG16 head, vgg16.py:98-101) */
 int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
+
+/* ==== layer programs and composed entry points (rpn_forward, train_step, predict_tile, allreduce_grads) ====
+ * A layer program is a static array of launches the host scheduler builds once per input size from the reference's graph
+ * (resnet50.py:150-281 nn_base / classifier_layer, rpn.py:12-66 rpn_layer, and their backward programs); radnet_program_run
+ * enqueues it on the context's stream.  No allocation, no synchronisation: running it on a capturing stream records it into
+ * a hipGraph.  Argument slots per kind (i = integers, p = device pointers):
+ *   CONV_FWD / CONV_DGRAD / CONV_WGRAD   conv
+ *   MAXPOOL      p: x, y                     i: nb, h, w, c, k, s
+ *   COLSUM       p: g, gscale|0, out         i: m, n, ld, accumulate
+ *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy   (radnet_winograd_input + 16 GEMMs
+ *   WINO_REUSE   same, v already holds this input's transform                                   + radnet_winograd_output)
+ *   WINO_WGRAD   p: dy, v, dz, du, dw        i: nb, h, w, c, n, ld_dy, tiles, ldw, accumulate mode (as radnet_conv_desc)
+ *   SCATTER      p: src, mask|0, dst         i: nb, oh, ow, c, stride, h, w
+ *   FILL0        p: dst                      i: bytes (low 32 bits), bytes (high 32 bits)
+ *   RELU_MASK    p: g, act                   i: n (low), n (high)
+ *   ROI_BWD      p: dy, rois, dfmap          i: h, w, c, r, ps */
+enum {
+  RADNET_OP_CONV_FWD = 1, RADNET_OP_CONV_DGRAD = 2, RADNET_OP_CONV_WGRAD = 3, RADNET_OP_MAXPOOL = 4, RADNET_OP_COLSUM = 5,
+  RADNET_OP_WINO = 6, RADNET_OP_WINO_REUSE = 7, RADNET_OP_WINO_WGRAD = 8, RADNET_OP_SCATTER = 9, RADNET_OP_FILL0 = 10,
+  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12
+};
+typedef struct radnet_op {
+  int32_t kind;
+  int32_t i[11];
+  const void* p[8];
+  radnet_conv_desc conv;
+} radnet_op;
+int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops);
+
+/* model_rpn.predict (RADNet.py:552; train.py:291): nn_base program, then rpn_layer program (outputs where the programs'
+ * descriptors point: the fused head matrix [fh*fw][ld] with the sigmoid scores in columns [0,A), regressions in [A,5A)). */
+int radnet_rpn_forward(radnet_ctx* ctx, const radnet_op* base_ops, int32_t n_base, const radnet_op* rpn_ops, int32_t n_rpn);
+
+/* classifier_layer on n_rois RoIs of one feature map (resnet50.py:231-281): RoI crop-resize, stage-5 program, avg-pool,
+ * dense heads.  rois [n_rois][4] fp32 (x,y,w,h); outputs p_cls [n_rois][nc] (softmax), p_regr [n_rois][nreg]. */
+typedef struct radnet_head_desc {
+  const float* fmap; int32_t fh, fw, fc;
+  const float* rois; int32_t n_rois, pool; float* pooled;
+  const radnet_op* fwd_ops; int32_t n_fwd;
+  const float* y5; int32_t hw, feat_c; float* feat;
+  const float* dense_w; int32_t dense_ld; const float* dense_b; int32_t nc, nreg;
+  float* p_cls; float* p_regr;
+} radnet_head_desc;
+
+/* One tile of RADNet.predict up to the classifier outputs (RADNet.py:520-600): preprocess (img_u8 != 0: uint8 BGR [h][w][3]
+ * -> x fp32 [h][w][4]), base + RPN programs, rpn.rpn_to_roi (decode + NMS, <= max_boxes RoIs in R / Rn), then -- when head is
+ * set -- the first head->n_rois proposals (padded with copies of the first, RADNet.py:115-122) through classifier_layer. */
+typedef struct radnet_tile_desc {
+  const uint8_t* img_u8; int32_t h, w; float* x;
+  const radnet_op* base_ops; int32_t n_base;
+  const radnet_op* rpn_ops; int32_t n_rpn;
+  const float* pred; int32_t ld_pred, fh, fw, a;
+  const double* anchor_wh_host; double std_scaling, overlap_thresh; int32_t max_boxes;
+  int64_t* R; float* Rp; int32_t* Rn; void* prop_ws;
+  const radnet_head_desc* head;
+} radnet_tile_desc;
+int radnet_predict_tile(radnet_ctx* ctx, const radnet_tile_desc* t);
+
+/* One flat optimizer arena (train.py:236-252: one Adam per model). */
+typedef struct radnet_adam_desc {
+  float* p; float* g; float* m; float* v; int64_t n; int32_t t; float lr;
+} radnet_adam_desc;
+
+/* The two places where a reference iteration draws from NumPy's GLOBAL random stream stay on the host, in the caller's RNG:
+ *   subsample_anchors  utils.py:785-813: valid / overlap uint8 [a][fh][fw] (host); edits valid in place; returns n_pos, or < 0
+ *                      when the labeller fails as the reference's does (the sample is skipped, utils.py:461-465);
+ *   select_rois        train.py:93-129: cls[n] class index per proposal (-1 = dropped by calc_iou); writes n_rois indices into
+ *                      the proposal list to sel; returns n_rois, or 0 when no proposal was kept (head step skipped). */
+typedef struct radnet_host_hooks {
+  void* user;
+  int32_t (*subsample_anchors)(void* user, uint8_t* valid, const uint8_t* overlap, int32_t a, int32_t fh, int32_t fw);
+  int32_t (*select_rois)(void* user, const int32_t* cls, int32_t n, int32_t* sel, int32_t n_rois);
+} radnet_host_hooks;
+
+/* One reference training iteration on one image (train.py:288-402), synchronous, on the context's stream:
+ * anchor targets -> base + RPN forward -> [hook] -> RPN losses / backward -> [all-reduce] -> Adam #1 -> re-prediction ->
+ * proposals -> RoI labelling -> [hook] -> classifier forward / losses / backward -> [all-reduce] -> Adam #2.  The caller owns
+ * every buffer (h_* are pinned host mirrors) and increments the optimizers' t before the call.  world > 1: the gradient
+ * arenas are summed over the communicator of radnet_comm_init and the update uses 1/world (one image per rank).
+ * losses5 = (rpn_cls, rpn_regr, det_cls, det_regr, det_acc); took_head_step = 1, 0 when the classifier step was skipped
+ * (no proposal kept), -1 when the labeller hook dropped the image (nothing was trained, no optimizer step). */
+typedef struct radnet_train_desc {
+  const uint8_t* img_u8; int32_t h, w; float* x;
+  const double* gt; const int32_t* gt_is_bg; const int32_t* gt_cls; int32_t g, width, height;
+  const double* anchor_sizes_host; int32_t ns; const double* anchor_ratios_host; int32_t nr;
+  double rpn_stride, rpn_max_overlap, std_scaling;
+  uint8_t* valid; uint8_t* overlap; double* regr; int32_t* best_anchor; int32_t* n_for_gt; void* at_scratch;
+  uint8_t* h_valid; uint8_t* h_overlap; float* y_cls; float* y_regr;
+  const radnet_op* base_ops; int32_t n_base;
+  const radnet_op* rpn_fwd_ops; int32_t n_rpn_fwd;
+  const radnet_op* rpn_bwd_ops; int32_t n_rpn_bwd;
+  const radnet_op* rpn_refwd_ops; int32_t n_rpn_refwd;
+  float* pred; float* dz; int32_t ld_pred, fh, fw, a, bce_mode; double* loss_scratch8; float* rpn_losses;
+  radnet_adam_desc rpn_opt, head_opt; int32_t world;
+  const float* wino_w; int32_t wino_c, wino_n, wino_ldw; float* wino_u;
+  const double* anchor_wh_host; double overlap_thresh; int32_t max_boxes;
+  int64_t* R; float* Rp; int32_t* Rn; void* prop_ws;
+  int32_t rw, rh; double min_overlap, max_overlap; const double* regr_std_host4; int32_t bg_class;
+  uint8_t* keep; int32_t* roi_cls; int32_t* roi_box; double* roi_t; double* roi_iou;
+  int32_t* h_roi_cls; int32_t* h_n; int32_t* sel; int32_t* h_sel;
+  const radnet_head_desc* head; float* y1; float* y2;
+  float* head_dz; float* det_losses; float* dense_dw; float* dense_db; float* dfeat; float* g_last;
+  const radnet_op* head_bwd_ops; int32_t n_head_bwd;
+  float* head_shift; const float* head_scale; const float* head_bias; const float* head_t0; int64_t head_bias_len;
+} radnet_train_desc;
+int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, const radnet_host_hooks* hooks, float* losses5,
+                      int32_t* took_head_step);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------------
+ * One communicator per context: rank 0 draws the id (radnet_comm_unique_id) and hands it to the other ranks through whatever
+ * rendezvous the job has (torch.distributed's store, a file, MPI); every rank then calls radnet_comm_init.  The collective
+ * is enqueued on the context's stream, in place, fp32 sum.  RCCL is bound at run time: RADNET_ERR_UNSUPPORTED without it. */
+int radnet_comm_unique_id(char out128[128]);
+int radnet_comm_init(radnet_ctx* ctx, int32_t world, int32_t rank, const char id128[128]);
+int radnet_comm_destroy(radnet_ctx* ctx);
+int radnet_allreduce_grads(radnet_ctx* ctx, float* grads, int64_t count);
 
 #ifdef __cplusplus
 }

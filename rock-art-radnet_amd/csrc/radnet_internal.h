@@ -58,7 +58,7 @@ struct radnet_ctx {
   // timing of GEMM-class launches with HIP events on `stream` (bench roofline leg)
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  radnet_timing_slot slots[3];
+  radnet_timing_slot slots[4];      // 0 fwd, 1 dgrad, 2 wgrad, 3 Winograd layers of a program
   // pending (not yet resolved) event pairs are resolved lazily to avoid a sync per launch
   static constexpr int kMaxPending = 4096;
   hipEvent_t pend0[kMaxPending];
@@ -69,6 +69,9 @@ struct radnet_ctx {
   int n_events_alloc = 0;
   // written only by the diagnostic build (make diag, -DRADNET_DIAG_STAMPS): per-workgroup s_memtime stamps
   unsigned long long* diag_stamps = nullptr;
+  // data-parallel exchange (program.hip): RCCL communicator of this context, bound at run time
+  void* comm = nullptr;
+  int comm_world = 0;
 };
 
 #define RADNET_FAIL(ctx, code, ...)                         \

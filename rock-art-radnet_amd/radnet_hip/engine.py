@@ -151,10 +151,10 @@ class FasterRCNNEngine:
         # 32 per kind: the training step keeps 6 buffer sets x images per GPU alive at once; beyond that, least recently used
         self._plans = PlanCache(int(os.environ.get("RADNET_PLAN_CACHE", "32")), self._evict_plan)
         self._graphs = {}
+        self._compiled = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
-        self.wino_timing = [0.0, 0.0, 0]        # ms, algorithmic flops, layers -- filled while ctx.timing is on (bench roofline leg)
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
         self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
@@ -466,6 +466,8 @@ class FasterRCNNEngine:
                 lists.update(id(p[0]) for p in v if isinstance(p, tuple) and p and isinstance(p[0], list))     # bwd_parts
         for gk in [k for k in self._graphs if k[0] in lists]:
             del self._graphs[gk]
+        for ck in [k for k in self._compiled if k[0] in lists]:
+            del self._compiled[ck]
 
     def save_tuning(self, path):
         """Write the measured GEMM launch choices of this engine (one table for all lanes) to a text file."""
@@ -537,76 +539,79 @@ class FasterRCNNEngine:
                 return self._run_eager(ops)
         ent[1].replay()
 
-    def _run_eager(self, ops):
-        lib, h = self.lib, self.ctx.h
-        for kind, p in ops:
-            if kind == "conv":
-                rc = lib.radnet_conv_fwd(h, C.byref(p))
-            elif kind == "dgrad":
-                rc = lib.radnet_conv_dgrad(h, C.byref(p))
-            elif kind == "wgrad":
-                rc = lib.radnet_conv_wgrad(h, C.byref(p))
+    def _compile(self, ops):
+        """The launch list as a radnet_op array (include/radnet_hip.h): what radnet_program_run executes and what the composed
+        entry points (radnet_rpn_forward / radnet_predict_tile / radnet_train_step) take.  Cached per list and gradient write
+        mode (set_accumulate edits the Python descriptors in place; the array holds copies)."""
+        key = (id(ops), tuple(p.dw_accumulate if kind == "wgrad" else (p[-1] if kind == "wino_wgrad" else p[6]) for kind, p in ops
+                              if kind in ("wgrad", "wino_wgrad", "colsum")))
+        ent = self._compiled.get(key)
+        if ent is not None:
+            return ent[0]
+        arr = (L.Op * max(len(ops), 1))()
+        ptr = lambda v: v.data_ptr() if hasattr(v, "data_ptr") else v
+        for k, (kind, p) in enumerate(ops):
+            o = arr[k]
+            if kind in ("conv", "dgrad", "wgrad"):
+                o.kind = {"conv": L.OP_CONV_FWD, "dgrad": L.OP_CONV_DGRAD, "wgrad": L.OP_CONV_WGRAD}[kind]
+                o.conv = p
             elif kind == "maxpool":
-                x, y, nb, hh, ww, c, k, s = p
-                rc = lib.radnet_maxpool_fwd(h, x.data_ptr(), y.data_ptr(), nb, hh, ww, c, k, s)
+                x, y, nb, hh, ww, c, kk, st = p
+                o.kind = L.OP_MAXPOOL
+                o.p[0], o.p[1] = ptr(x), ptr(y)
+                o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5] = nb, hh, ww, c, kk, st
             elif kind == "colsum":
                 g, m, n, ld, gs, out, acc = p
-                rc = lib.radnet_colsum(h, g, m, n, ld, gs, out, acc)
-            elif kind in ("wino", "wino_reuse"):   # ("wino_reuse": V already holds this input's transform)
-                # stride-1 'same' 3x3 conv as Winograd F(2x2,3x3): transform, 16 GEMMs, transform
+                o.kind = L.OP_COLSUM
+                o.p[0], o.p[1], o.p[2] = ptr(g), ptr(gs), ptr(out)
+                o.i[0], o.i[1], o.i[2], o.i[3] = m, n, ld, acc
+            elif kind in ("wino", "wino_reuse"):
                 x, nb, hh, ww, c, n, V, U, M, T, scale, shift, act, y, ldy = p
-                timed = self.ctx.timing_on
-                if timed:                  # roofline leg: the LAYER is timed (three kernels) and credited its algorithmic flops
-                    self.ctx.timing(False)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                rc = lib.radnet_winograd_input(h, x, nb, hh, ww, c, V) if kind == "wino" else 0
-                if rc == 0:
-                    rc = lib.radnet_gemm_batched(h, V, U, M, 16, T, n, c)
-                if rc == 0:
-                    rc = lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
-                if timed:
-                    e1.record()
-                    e1.synchronize()
-                    self.wino_timing[0] += e0.elapsed_time(e1)
-                    self.wino_timing[1] += 2.0 * nb * hh * ww * n * 9 * c
-                    self.wino_timing[2] += 1
-                    self.ctx.timing(True)
-            elif kind == "wino_wgrad":     # weight gradient of a Winograd layer in the transformed domain, on the forward's V
+                o.kind = L.OP_WINO if kind == "wino" else L.OP_WINO_REUSE
+                for j, v in enumerate((x, V, U, M, scale, shift, y)):
+                    o.p[j] = ptr(v)
+                for j, v in enumerate((nb, hh, ww, c, n, T, act, ldy)):
+                    o.i[j] = v
+            elif kind == "wino_wgrad":
                 dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, mode = p
-                timed = self.ctx.timing_on
-                if timed:
-                    self.ctx.timing(False)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                rc = lib.radnet_winograd_dy(h, dy, nb, hh, ww, n, ld_dy, None, dZ)
-                if rc == 0:
-                    rc = lib.radnet_wgrad_batched(h, V, dZ, dU, 16, T, c, n, 0)
-                if rc == 0:
-                    rc = lib.radnet_winograd_filter_grad(h, dU, c, n, ldw, dw, 1 if mode == 1 else 0)
-                if timed:
-                    e1.record()
-                    e1.synchronize()
-                    self.wino_timing[0] += e0.elapsed_time(e1)
-                    self.wino_timing[1] += 2.0 * nb * hh * ww * n * 9 * c
-                    self.wino_timing[2] += 1
-                    self.ctx.timing(True)
-            elif kind == "scatter":        # strided 1x1 dgrad: compact rows -> full grid (+ producer's ReLU mask)
+                o.kind = L.OP_WINO_WGRAD
+                for j, v in enumerate((dy, V, dZ, dU, dw)):
+                    o.p[j] = ptr(v)
+                for j, v in enumerate((nb, hh, ww, c, n, ld_dy, T, ldw, mode)):
+                    o.i[j] = v
+            elif kind == "scatter":
                 src, nb, oh, ow, c, st, hh, ww, mask, dst = p
-                rc = lib.radnet_scatter_strided(h, src, nb, oh, ow, c, st, hh, ww, mask, dst)
+                o.kind = L.OP_SCATTER
+                o.p[0], o.p[1], o.p[2] = ptr(src), ptr(mask), ptr(dst)
+                for j, v in enumerate((nb, oh, ow, c, st, hh, ww)):
+                    o.i[j] = v
             elif kind == "fill0":
-                ptr, nbytes = p
-                rc = lib.radnet_fill_zero(h, ptr, nbytes)
+                dst, nbytes = p
+                o.kind = L.OP_FILL0
+                o.p[0] = ptr(dst)
+                o.i[0], o.i[1] = C.c_int32(nbytes & 0xFFFFFFFF).value, int(nbytes) >> 32
             elif kind == "relu_mask":
                 g, act, n = p
-                rc = lib.radnet_relu_mask(h, g, act, n)
+                o.kind = L.OP_RELU_MASK
+                o.p[0], o.p[1] = ptr(g), ptr(act)
+                o.i[0], o.i[1] = C.c_int32(n & 0xFFFFFFFF).value, int(n) >> 32
             elif kind == "roi_bwd":
                 dy, hh, ww, c, rois, r, ps, dF = p
-                rc = lib.radnet_roi_resize_bwd(h, dy, hh, ww, c, rois, r, ps, dF)
+                o.kind = L.OP_ROI_BWD
+                o.p[0], o.p[1], o.p[2] = ptr(dy), ptr(rois), ptr(dF)
+                for j, v in enumerate((hh, ww, c, r, ps)):
+                    o.i[j] = v
             else:
                 raise L.RadnetError("unknown op " + kind)
-            if rc != 0:
-                self.ctx.check(rc, kind)
+        self._compiled[key] = (arr, ops)              # holds `ops` so its id stays unique
+        return arr
+
+    def _run_eager(self, ops):
+        """One native call per program (csrc/program.hip); Winograd layers are timed per layer inside it while ctx.timing is on
+        (timing class 3, read back by bench.py's roofline leg)."""
+        rc = self.lib.radnet_program_run(self.ctx.h, self._compile(ops), len(ops))
+        if rc != 0:
+            self.ctx.check(rc, "radnet_program_run")
 
     @staticmethod
     def _fuse_bias_grads(ops):

@@ -39,6 +39,76 @@ class ConvDesc(C.Structure):
     ]
 
 
+# ---- layer programs and composed entry points (include/radnet_hip.h, csrc/program.hip) --------------------------------
+OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_MAXPOOL, OP_COLSUM, OP_WINO, OP_WINO_REUSE, OP_WINO_WGRAD, OP_SCATTER, OP_FILL0, \
+    OP_RELU_MASK, OP_ROI_BWD = range(1, 13)
+
+
+class Op(C.Structure):
+    """Mirror of `radnet_op`: one launch of a layer program."""
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 11), ("p", C.c_void_p * 8), ("conv", ConvDesc)]
+
+
+class HeadDesc(C.Structure):
+    """Mirror of `radnet_head_desc`."""
+    _fields_ = [("fmap", C.c_void_p), ("fh", C.c_int32), ("fw", C.c_int32), ("fc", C.c_int32),
+                ("rois", C.c_void_p), ("n_rois", C.c_int32), ("pool", C.c_int32), ("pooled", C.c_void_p),
+                ("fwd_ops", C.POINTER(Op)), ("n_fwd", C.c_int32),
+                ("y5", C.c_void_p), ("hw", C.c_int32), ("feat_c", C.c_int32), ("feat", C.c_void_p),
+                ("dense_w", C.c_void_p), ("dense_ld", C.c_int32), ("dense_b", C.c_void_p), ("nc", C.c_int32), ("nreg", C.c_int32),
+                ("p_cls", C.c_void_p), ("p_regr", C.c_void_p)]
+
+
+class TileDesc(C.Structure):
+    """Mirror of `radnet_tile_desc`."""
+    _fields_ = [("img_u8", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("x", C.c_void_p),
+                ("base_ops", C.POINTER(Op)), ("n_base", C.c_int32),
+                ("rpn_ops", C.POINTER(Op)), ("n_rpn", C.c_int32),
+                ("pred", C.c_void_p), ("ld_pred", C.c_int32), ("fh", C.c_int32), ("fw", C.c_int32), ("a", C.c_int32),
+                ("anchor_wh_host", C.POINTER(C.c_double)), ("std_scaling", C.c_double), ("overlap_thresh", C.c_double), ("max_boxes", C.c_int32),
+                ("R", C.c_void_p), ("Rp", C.c_void_p), ("Rn", C.c_void_p), ("prop_ws", C.c_void_p),
+                ("head", C.POINTER(HeadDesc))]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64), ("t", C.c_int32), ("lr", C.c_float)]
+
+
+SUBSAMPLE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32)
+SELECT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32)
+
+
+class HostHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("subsample_anchors", SUBSAMPLE_FN), ("select_rois", SELECT_FN)]
+
+
+class TrainDesc(C.Structure):
+    """Mirror of `radnet_train_desc` (field order is the header's)."""
+    _d, _i, _vp = C.c_double, C.c_int32, C.c_void_p
+    _fields_ = [("img_u8", _vp), ("h", _i), ("w", _i), ("x", _vp),
+                ("gt", _vp), ("gt_is_bg", _vp), ("gt_cls", _vp), ("g", _i), ("width", _i), ("height", _i),
+                ("anchor_sizes_host", C.POINTER(_d)), ("ns", _i), ("anchor_ratios_host", C.POINTER(_d)), ("nr", _i),
+                ("rpn_stride", _d), ("rpn_max_overlap", _d), ("std_scaling", _d),
+                ("valid", _vp), ("overlap", _vp), ("regr", _vp), ("best_anchor", _vp), ("n_for_gt", _vp), ("at_scratch", _vp),
+                ("h_valid", _vp), ("h_overlap", _vp), ("y_cls", _vp), ("y_regr", _vp),
+                ("base_ops", C.POINTER(Op)), ("n_base", _i),
+                ("rpn_fwd_ops", C.POINTER(Op)), ("n_rpn_fwd", _i),
+                ("rpn_bwd_ops", C.POINTER(Op)), ("n_rpn_bwd", _i),
+                ("rpn_refwd_ops", C.POINTER(Op)), ("n_rpn_refwd", _i),
+                ("pred", _vp), ("dz", _vp), ("ld_pred", _i), ("fh", _i), ("fw", _i), ("a", _i), ("bce_mode", _i), ("loss_scratch8", _vp), ("rpn_losses", _vp),
+                ("rpn_opt", AdamDesc), ("head_opt", AdamDesc), ("world", _i),
+                ("wino_w", _vp), ("wino_c", _i), ("wino_n", _i), ("wino_ldw", _i), ("wino_u", _vp),
+                ("anchor_wh_host", C.POINTER(_d)), ("overlap_thresh", _d), ("max_boxes", _i),
+                ("R", _vp), ("Rp", _vp), ("Rn", _vp), ("prop_ws", _vp),
+                ("rw", _i), ("rh", _i), ("min_overlap", _d), ("max_overlap", _d), ("regr_std_host4", C.POINTER(_d)), ("bg_class", _i),
+                ("keep", _vp), ("roi_cls", _vp), ("roi_box", _vp), ("roi_t", _vp), ("roi_iou", _vp),
+                ("h_roi_cls", _vp), ("h_n", _vp), ("sel", _vp), ("h_sel", _vp),
+                ("head", C.POINTER(HeadDesc)), ("y1", _vp), ("y2", _vp),
+                ("head_dz", _vp), ("det_losses", _vp), ("dense_dw", _vp), ("dense_db", _vp), ("dfeat", _vp), ("g_last", _vp),
+                ("head_bwd_ops", C.POINTER(Op)), ("n_head_bwd", _i),
+                ("head_shift", _vp), ("head_scale", _vp), ("head_bias", _vp), ("head_t0", _vp), ("head_bias_len", C.c_int64)]
+
+
 def declared_symbols():
     """Names of every function the public header declares."""
     with open(HEADER_PATH) as f:
@@ -115,6 +185,14 @@ def load_library():
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_resize_bicubic_u8": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),
+        "radnet_program_run": (C.c_int, [vp, C.POINTER(Op), i32]),
+        "radnet_rpn_forward": (C.c_int, [vp, C.POINTER(Op), i32, C.POINTER(Op), i32]),
+        "radnet_predict_tile": (C.c_int, [vp, C.POINTER(TileDesc)]),
+        "radnet_train_step": (C.c_int, [vp, C.POINTER(TrainDesc), C.POINTER(HostHooks), C.POINTER(C.c_float), C.POINTER(i32)]),
+        "radnet_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "radnet_comm_init": (C.c_int, [vp, i32, i32, C.c_char_p]),
+        "radnet_comm_destroy": (C.c_int, [vp]),
+        "radnet_allreduce_grads": (C.c_int, [vp, vp, i64]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
     }
     for name, (res, args) in sig.items():

@@ -1,0 +1,122 @@
+"""Composed C-ABI entry points (include/radnet_hip.h, csrc/program.hip; SURVEY.md 8b "minimum exports") against the
+scheduler-driven path on the same engine -- the SAME kernels in the same order, so results must agree bit for bit -- and,
+through it, against the oracle (tests/test_gpu_engine.py covers the scheduler path against the oracle):
+
+  radnet_rpn_forward     base program + RPN program                          == engine.base_forward + engine.rpn_forward
+  radnet_predict_tile    preprocess .. proposals .. classifier outputs        == the NumPy-facing model calls RADNet makes
+  radnet_train_step      one reference iteration, RNG steps as host callbacks == trainer.TrainStep on one lane
+  radnet_comm_init / radnet_allreduce_grads   1-rank RCCL communicator: identity all-reduce on the context's stream"""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make(C=None, img_size=300):
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip.engine import FasterRCNNEngine
+    C = C or Config()
+    C.img_size = img_size
+    P = dense.init_params(seed=3)
+    eng = FasterRCNNEngine(C)
+    eng.set_weights(P)
+    return C, P, eng
+
+
+def sample(i=0):
+    from radnet_hip import synth
+    meta = synth.synthetic_gt(40 + i, n=6, src_w=1000, src_h=600, smin=60, smax=300)
+    return dict(img=synth.synthetic_panel(30 + i, 300, 500), bboxes=meta["bboxes"], width=1000, height=600)
+
+
+def test_rpn_forward_composed_equals_program_by_program():
+    from radnet_hip import native
+    C, P, eng = make()
+    img = sample()["img"]
+    bp = eng.upload_image(img)
+    eng.base_forward(bp)
+    rp = eng.rpn_forward(bp)
+    want_F, want = bp["F"].cpu().numpy().copy(), rp["pred"].cpu().numpy().copy()
+    bp["F"].zero_(); rp["pred"].zero_()
+    rp2 = native.rpn_forward(eng, bp)
+    assert rp2 is rp
+    assert np.array_equal(bp["F"].cpu().numpy(), want_F) and np.array_equal(rp["pred"].cpu().numpy(), want)
+
+
+def test_predict_tile_composed_equals_model_calls():
+    from faster_rcnn import models as M
+    from faster_rcnn import rpn
+    from faster_rcnn.base_models import resnet50
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip import native
+    C = Config(); C.img_size = 300
+    P = dense.init_params(seed=3)
+    m_rpn, m_cls, m_all, m_rpn3, m_det = M.build_models(C, weights=copy.deepcopy(P))
+    eng = m_all._s.eng
+    img = np.random.RandomState(11).randint(0, 256, (300, 420, 3)).astype(np.uint8)
+    R, pc, pr = native.predict_tile(eng, torch.from_numpy(img).cuda(), 40)
+    X = resnet50.preprocess(img[:, :, (2, 1, 0)].astype(np.float32)[None])
+    Y1, Y2, F = m_rpn3.predict(X)
+    R_ref = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
+    assert np.array_equal(R, R_ref)
+    rois = R_ref[:40].copy(); rois[:, 2] -= rois[:, 0]; rois[:, 3] -= rois[:, 1]
+    pc_ref, pr_ref = m_det.predict([F, rois[None]])
+    assert np.array_equal(pc, pc_ref[0]) and np.array_equal(pr, pr_ref[0])
+
+
+def test_train_step_composed_equals_scheduler_one_lane():
+    """Three iterations through radnet_train_step == three TrainStep.step calls (one lane): losses, RNG consumption, RoI
+    selection, and every trainable weight."""
+    from radnet_hip import native
+    from radnet_hip.trainer import TrainStep
+    batches = [sample(i) for i in range(3)]
+    C, P, eng_a = make()
+    np.random.seed(64)
+    ts = TrainStep(eng_a)
+    ts.capture = []
+    la = []
+    for s in batches:
+        ts.step([s])
+        la.append(ts.losses())
+    rng_a = int(np.random.randint(0, 2 ** 31 - 1))
+    wa = eng_a.get_weights()
+    tune = "/tmp/radnet_native_tune.txt"
+    eng_a.save_tuning(tune)
+    C2, P2, eng_b = make()
+    eng_b.load_tuning(tune)                          # same launch shapes -> same summation order
+    np.random.seed(64)
+    nt = native.NativeTrainStep(eng_b)
+    nt.capture = []
+    lb = []
+    for s in batches:
+        lb.append(nt.step(s).losses())
+    rng_b = int(np.random.randint(0, 2 ** 31 - 1))
+    wb = eng_b.get_weights()
+    assert rng_a == rng_b
+    for a, b, ca, cb in zip(la, lb, ts.capture, nt.capture):
+        assert a["n_head"] == b["n_head"] == 1
+        assert ca["sel_kept"] == cb["sel_kept"] and np.array_equal(ca["R"], cb["R"])
+        for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+    for name in wa:
+        for k in wa[name]:
+            assert np.allclose(wa[name][k], wb[name][k], rtol=0, atol=2e-7), (name, k)     # split wgrad sums with fp32 atomics
+
+
+def test_allreduce_grads_one_rank_communicator():
+    from radnet_hip import native
+    C, P, eng = make()
+    native.comm_init(eng, 1, 0)
+    g = eng.rpn_arena.g
+    g.copy_(torch.arange(g.numel(), dtype=torch.float32, device=g.device) % 1000)
+    want = g.cpu().numpy().copy()
+    native.allreduce(eng, g)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy(), want)
+    eng.ctx.check(eng.lib.radnet_comm_destroy(eng.ctx.h), "comm_destroy")
+    g.zero_()
