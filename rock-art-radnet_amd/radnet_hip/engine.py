@@ -153,6 +153,8 @@ class FasterRCNNEngine:
         self._graphs = {}
         self._compiled = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
+        # classifier tail (avg-pool, dense heads, detector losses and their backward) as two launches instead of five
+        self.fuse_tail = os.environ.get("RADNET_NO_TAIL_FUSION", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
@@ -919,7 +921,11 @@ class FasterRCNNEngine:
             raise RuntimeError("head gradient buckets do not tile the kernel part of the arena: %r" % (cover,))
         if [sl for _, sl in bwd_parts] != self.head_exchange_slices():
             raise RuntimeError("head backward parts and head_exchange_slices() disagree")
+        tail_scratch = torch.zeros(int(self.lib.radnet_head_tail_scratch_bytes(R)), dtype=torch.uint8, device=dev)
+        live = torch.ones(groups, dtype=torch.int32, device=dev)
+        keep += [tail_scratch, live]
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
+                    tail_scratch=tail_scratch, live=live, live_host=[1] * groups,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep, groups=groups)
         self._plans[key] = plan
         return plan
@@ -946,8 +952,11 @@ class FasterRCNNEngine:
                 self._head_slices = sl[::-1]
         return self._head_slices
 
-    def head_forward(self, hp, training=False):
-        """classifier_layer forward (`training` only matters for the VGG16 head's Dropout)."""
+    def head_forward(self, hp, training=False, loss_out=None, group_live=None):
+        """classifier_layer forward (`training` only matters for the VGG16 head's Dropout).  loss_out (training plans whose
+        targets y1 / y2 are already packed): the detector losses (row g of loss_out for group g: cls, regr, accuracy) and the
+        gradient w.r.t. the logits are computed in the same launch as the dense heads (csrc/head_tail.hip); head_backward
+        then skips its loss pass.  group_live: per group 0/1 -- 0 = that image takes no classifier step (zero gradient rows)."""
         G = hp.get("groups", 1)
         if G == 1:
             self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
@@ -956,6 +965,20 @@ class FasterRCNNEngine:
             for g in range(G):                  # RoIs of image g crop feature map g
                 self.ctx.call("radnet_roi_resize_fwd", hp["F"][g], hp["fh"], hp["fw"], 1024, hp["rois"][g * rg:], rg, 14, hp["pooled"][g * rg:])
         self._run(hp["fwd"])
+        hp["_tail_fused"] = False
+        if self.fuse_tail:
+            fused_loss = training and loss_out is not None and "tail_scratch" in hp
+            if fused_loss:
+                flags = [1] * G if group_live is None else [1 if f else 0 for f in group_live]
+                if flags != hp["live_host"]:
+                    hp["live"].copy_(torch.tensor(flags, dtype=torch.int32), non_blocking=False)
+                    hp["live_host"] = flags
+            self.ctx.call("radnet_head_tail_fwd", hp["y5"], hp["R"], hp["hw"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
+                          hp["feat"], hp["pcls"], hp["pregr"], hp["y1"] if fused_loss else None, hp["y2"] if fused_loss else None,
+                          hp["dz"] if fused_loss else None, loss_out if fused_loss else None, G, hp["live"] if fused_loss else None,
+                          hp["tail_scratch"] if fused_loss else None)
+            hp["_tail_fused"] = fused_loss
+            return
         self.ctx.call("radnet_avgpool_fwd", hp["y5"], hp["R"], hp["hw"], 2048, hp["feat"])
         self.ctx.call("radnet_dense_heads_fwd", hp["feat"], hp["R"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                       hp["pcls"], hp["pregr"])
@@ -967,7 +990,9 @@ class FasterRCNNEngine:
         while the earlier blocks are still being differentiated; the biases and the dense heads (the arena's tail from
         head_bias_off) are complete when the call returns."""
         G = hp.get("groups", 1)
-        if G == 1:
+        if hp.get("_tail_fused"):
+            pass                              # losses + dz came out of head_forward's launch
+        elif G == 1:
             self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
                           self.det_losses if loss_out is None else loss_out)
         else:
@@ -981,9 +1006,13 @@ class FasterRCNNEngine:
                     continue
                 self.ctx.call("radnet_det_loss", hp["pcls"][g * rg:], hp["pregr"][g * rg:], hp["y1"][g * rg:], hp["y2"][g * rg:], rg, self.nc,
                               self.nreg, hp["dz"][g * rg:], lo)
-        self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
-                      self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
-        self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
+        if self.fuse_tail and "tail_scratch" in hp:
+            self.ctx.call("radnet_head_tail_bwd", hp["feat"], hp["dz"], hp["y5"], hp["R"], hp["hw"], 2048, self.dense_w, self.dense_ld,
+                          self.nc + self.nreg, self.dense_dw, self.dense_db, hp["dfeat"], hp["g_last"], 1 if accumulate else 0)
+        else:
+            self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
+                          self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
+            self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
         if on_part is None or "bwd_parts" not in hp:
             self._run(hp["bwd"])
             return

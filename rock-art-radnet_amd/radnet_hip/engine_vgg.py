@@ -223,7 +223,7 @@ class VGG16Engine(FasterRCNNEngine):
         hp["m1"].copy_(torch.from_numpy(np.ascontiguousarray(m1, dtype=np.float32)))
         hp["m2"].copy_(torch.from_numpy(np.ascontiguousarray(m2, dtype=np.float32)))
 
-    def head_forward(self, hp, training=False):
+    def head_forward(self, hp, training=False, loss_out=None, group_live=None):     # (loss_out: the fc head keeps its separate loss pass)
         """vgg16.classifier_layer forward; Dropout only when `training` (keras learning phase)."""
         n = hp["R"] * 4096
         self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 512, hp["rois"], hp["R"], POOL, hp["pooled"])

@@ -106,7 +106,8 @@ class TrainDesc(C.Structure):
                 ("head", C.POINTER(HeadDesc)), ("y1", _vp), ("y2", _vp),
                 ("head_dz", _vp), ("det_losses", _vp), ("dense_dw", _vp), ("dense_db", _vp), ("dfeat", _vp), ("g_last", _vp),
                 ("head_bwd_ops", C.POINTER(Op)), ("n_head_bwd", _i),
-                ("head_shift", _vp), ("head_scale", _vp), ("head_bias", _vp), ("head_t0", _vp), ("head_bias_len", C.c_int64)]
+                ("head_shift", _vp), ("head_scale", _vp), ("head_bias", _vp), ("head_t0", _vp), ("head_bias_len", C.c_int64),
+                ("tail_scratch", _vp)]
 
 
 def declared_symbols():
@@ -166,6 +167,9 @@ def load_library():
         "radnet_avgpool_bwd_relu": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "radnet_dense_heads_fwd": (C.c_int, [vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp]),
         "radnet_dense_heads_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32]),
+        "radnet_head_tail_scratch_bytes": (u64, [i32]),
+        "radnet_head_tail_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "radnet_head_tail_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32]),
         "radnet_rpn_loss": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
         "radnet_det_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32]),

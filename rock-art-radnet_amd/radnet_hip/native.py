@@ -160,6 +160,7 @@ class NativeTrainStep:
             d.head_shift, d.head_scale, d.head_t0 = eng.head_shift.data_ptr(), eng.head_scale.data_ptr(), eng.head_t0.data_ptr()
             d.head_bias = ha.p[eng.head_bias_off:].data_ptr()
             d.head_bias_len = eng.head_bias_len
+            d.tail_scratch = hp["tail_scratch"].data_ptr()
             ent = self._descs[key] = (d, buf, head, bp, rp, hp)
         return ent
 

@@ -394,6 +394,7 @@ class TrainStep:
         head_lane = (lambda: eng.lane("head")) if lanes else contextlib.nullcontext
         slot = st["slot"]
         n_head = 0
+        det_rows = None                 # rows of the detector-loss slots that hold this step's losses (default: the first n_head)
         live = [i for i in range(nloc) if picks[i] is not None]
         # Bucketed exchange (deferred mode): during the LAST local image's backward each block's kernel gradients are
         # final as soon as that block is differentiated -- their all-reduce starts then, beside the blocks still to come
@@ -418,10 +419,11 @@ class TrainStep:
                         slots.append(None)
                     else:
                         eng.pack_roi_batch(picks[i][0], picks[i][1], hp, group=i)
-                        slots.append(self._det_l[slot][n_head])
+                        slots.append(self._det_l[slot][i])            # row i = image i of the mini-batch
                         n_head += 1
+                det_rows = [i for i in range(nloc) if picks[i] is not None]
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
-                eng.head_forward(hp, training=True)
+                eng.head_forward(hp, training=True, loss_out=self._det_l[slot], group_live=[p is not None for p in picks])
                 eng.set_accumulate(hp["bwd"], False, prezeroed=True)
                 eng.head_backward(hp, accumulate=True, loss_out=slots, on_part=exchange if bucketed else None)
             for i, bp in enumerate(st["plans"] if not st.get("stacked") else []):
@@ -430,7 +432,7 @@ class TrainStep:
                 hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
                 eng.pack_roi_batch(picks[i][0], picks[i][1], hp)
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
-                eng.head_forward(hp, training=True)
+                eng.head_forward(hp, training=True, loss_out=self._det_l[slot][n_head])
                 eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
                 if bucketed and i == live[-1]:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head], on_part=exchange)
@@ -454,16 +456,16 @@ class TrainStep:
             if lanes:
                 self._head_last = self._head_done[slot] = eng.mark()
         mark("D: head forward + backward + adam enqueued")
-        self.last = (nloc, n_head, slot, list(st.get("dead", [False] * nloc)))
+        self.last = (nloc, n_head, slot, list(st.get("dead", [False] * nloc)), det_rows if det_rows is not None else list(range(n_head)))
         return self
 
     def losses(self):
         """Host copy of the last step's mean losses (one device sync)."""
-        nloc, n_head, slot, dead = self.last
+        nloc, n_head, slot, dead, det_rows = self.last
         if self._head_last is not None:
             self._head_last.synchronize()            # the head lane wrote the detector losses
         live = [i for i in range(nloc) if not dead[i]]
         r = self._rpn_l[slot][:nloc].cpu().numpy()[live].mean(0) if live else np.full(2, np.nan, np.float32)
-        d = self._det_l[slot][:max(n_head, 1)].cpu().numpy().mean(0) if n_head else np.zeros(3, np.float32)
+        d = self._det_l[slot].cpu().numpy()[det_rows].mean(0) if n_head else np.zeros(3, np.float32)
         return {"rpn_cls": float(r[0]), "rpn_regr": float(r[1]), "det_cls": float(d[0]), "det_regr": float(d[1]), "det_acc": float(d[2]),
                 "n_head": n_head, "dropped": nloc - len(live)}

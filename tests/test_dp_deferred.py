@@ -105,7 +105,7 @@ class FakeEngine:
     def pack_roi_batch(self, P, sel, hp):
         pass
 
-    def head_forward(self, hp, training=False):
+    def head_forward(self, hp, training=False, loss_out=None, group_live=None):
         self.log.append(("head_fwd", self.k, float(self.head_arena.p[0])))
 
     def head_backward(self, hp, accumulate=True, loss_out=None, on_part=None):

@@ -317,9 +317,12 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead, sta
         assert a["n_head"] == b["n_head"] == 1
         for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
             assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+    # wgrad sums its K slices with fp32 atomics (order varies from run to run) and Adam turns a last-bit difference of a tiny
+    # gradient into a visible fraction of lr = 5e-5: almost every weight agrees to the last bits, none moves by more than lr / 10
     for name in ("rpn_conv1", "rpn_out_class", "res5a_branch2a", "res5c_branch2c", "dense_class_7"):
         for k in ("kernel", "bias"):
-            assert np.allclose(w0[name][k], w1[name][k], rtol=0, atol=2e-7), (name, k)
+            d = np.abs(w0[name][k] - w1[name][k])
+            assert d.max() < 5e-6 and np.mean(d < 3e-7) > 0.999, (name, k, float(d.max()), float(np.mean(d < 3e-7)))
 
 
 def test_changed_announcement_is_refused():

@@ -510,3 +510,60 @@ def test_winograd_wgrad_vs_oracle(ctx, case):
     close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
     ctx.call("radnet_winograd_filter_grad", dU, cin, cout, cout, dw, 1)          # accumulate: doubles
     close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
+
+
+@pytest.mark.parametrize("groups,idle", [(1, None), (2, None), (2, 1)])
+def test_head_tail_fused_equals_separate_kernels(ctx, groups, idle):
+    """csrc/head_tail.hip (avg-pool + dense heads + detector losses in one launch; dense + avg-pool backward in one) against
+    the five separate kernels it replaces on the training step -- which tests/test_gpu_engine.py pins against the oracle."""
+    rs = np.random.RandomState(3 + groups)
+    rg, nc, nreg, hw, c, ld = 20, 7, 24, 49, 2048, 32
+    R = rg * groups
+    y5 = np.maximum(rs.standard_normal((R, hw, c)), 0).astype(np.float32)
+    w = np.zeros((c, ld), np.float32); w[:, :nc + nreg] = rs.standard_normal((c, nc + nreg)) * 0.02
+    b = np.zeros(ld, np.float32); b[:nc + nreg] = rs.standard_normal(nc + nreg) * 0.1
+    cls = rs.randint(0, nc, R)
+    y1 = np.eye(nc, dtype=np.float32)[cls]
+    lab = np.zeros((R, nreg), np.float32)
+    for i, k in enumerate(cls):
+        if k != nc - 1:
+            lab[i, 4 * k:4 * k + 4] = 1
+    y2 = np.concatenate([lab, (rs.standard_normal((R, nreg)) * 2).astype(np.float32) * lab], 1)
+    d = {k: dev(v) for k, v in dict(y5=y5, w=w, b=b, y1=y1, y2=y2).items()}
+    z = lambda *s: torch.full(s, float("nan"), device="cuda")
+    # ---- separate kernels
+    feat0, pc0, pr0, dz0, dw0, db0, df0, gl0 = z(R, c), z(R, nc), z(R, nreg), z(R, nc + nreg), z(c, ld), z(ld), z(R, c), z(R, hw, c)
+    L0 = torch.zeros(groups, 3, device="cuda")
+    ctx.call("radnet_avgpool_fwd", d["y5"], R, hw, c, feat0)
+    ctx.call("radnet_dense_heads_fwd", feat0, R, c, d["w"], ld, d["b"], nc, nreg, pc0, pr0)
+    for g in range(groups):
+        o = g * rg
+        if idle == g:
+            dz0[o:o + rg].zero_()
+            continue
+        ctx.call("radnet_det_loss", pc0[o:], pr0[o:], d["y1"][o:], d["y2"][o:], rg, nc, nreg, dz0[o:], L0[g])
+    ctx.call("radnet_dense_heads_bwd", feat0, dz0, R, c, d["w"], ld, nc + nreg, dw0, db0, df0, 0)
+    ctx.call("radnet_avgpool_bwd_relu", df0, d["y5"], R, hw, c, gl0)
+    # ---- fused
+    feat1, pc1, pr1, dz1, dw1, db1, df1, gl1 = z(R, c), z(R, nc), z(R, nreg), z(R, nc + nreg), z(c, ld), z(ld), z(R, c), z(R, hw, c)
+    L1 = torch.zeros(groups, 3, device="cuda")
+    scratch = torch.zeros(int(ctx.lib.radnet_head_tail_scratch_bytes(R)), dtype=torch.uint8, device="cuda")
+    live = torch.tensor([0 if idle == g else 1 for g in range(groups)], dtype=torch.int32, device="cuda")
+    for _ in range(2):                                    # twice: the arrival counter must be back at zero after a launch
+        ctx.call("radnet_head_tail_fwd", d["y5"], R, hw, c, d["w"], ld, d["b"], nc, nreg, feat1, pc1, pr1, d["y1"], d["y2"], dz1, L1, groups, live, scratch)
+    ctx.call("radnet_head_tail_bwd", feat1, dz1, d["y5"], R, hw, c, d["w"], ld, nc + nreg, dw1, db1, df1, gl1, 0)
+    ctx.sync()
+    assert np.array_equal(feat1.cpu().numpy(), feat0.cpu().numpy())             # same pooling arithmetic
+    for a, bb, tol in ((pc1, pc0, 1e-5), (pr1, pr0, 1e-5), (dz1, dz0, 1e-5), (dw1, dw0, 1e-5), (db1, db0, 1e-5), (df1, df0, 1e-5), (gl1, gl0, 1e-5)):
+        close(a.cpu().numpy(), bb.cpu().numpy(), rtol=tol, atol=1e-7)
+    close(L1.cpu().numpy(), L0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert np.all(np.isfinite(dw1.cpu().numpy())) and (idle is None or float(dz1[idle * rg:(idle + 1) * rg].abs().max()) == 0.0)
+    # inference form: no targets, no losses
+    pc2, pr2, feat2 = z(R, nc), z(R, nreg), z(R, c)
+    ctx.call("radnet_head_tail_fwd", d["y5"], R, hw, c, d["w"], ld, d["b"], nc, nreg, feat2, pc2, pr2, None, None, None, None, 1, None, None)
+    ctx.sync()
+    assert np.array_equal(pc2.cpu().numpy(), pc1.cpu().numpy()) and np.array_equal(pr2.cpu().numpy(), pr1.cpu().numpy())
+    # accumulate mode of the backward
+    ctx.call("radnet_head_tail_bwd", feat1, dz1, d["y5"], R, hw, c, d["w"], ld, nc + nreg, dw1, db1, df1, gl1, 1)
+    ctx.sync()
+    close(dw1.cpu().numpy(), 2 * dw0.cpu().numpy(), rtol=1e-5, atol=1e-7)
