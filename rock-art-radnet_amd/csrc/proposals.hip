@@ -4,8 +4,14 @@
 //
 //   decode   one thread per anchor (a,row,col): delta decode, round-half-even, clamp, clip, validity;
 //            emits a 64-bit sort key (order-preserving score bits << 32 | flat index), 0 for dropped boxes.
-//   sort     descending device radix sort of the keys (rocPRIM, header-only) -> "stable ascending,
-//            walk from the end": among equal scores the higher flat index comes first.
+//   rpn_to_roi (the hot path; coordinates are integers after np.round + clip): ONE launch of ONE workgroup does the rest --
+//            select_nms_kernel: a radix SELECT over the keys (11-bit digits, histogram in LDS) finds the lower bound of the best
+//            <= 4096 not yet examined, those keys are gathered into LDS, bitonic-sorted there (descending = "stable ascending,
+//            walk from the end": among equal scores the higher flat index first) and fed to the greedy NMS below with exact
+//            INTEGER intersection / union arithmetic; if 300 picks are not reached the next band follows.  Work is
+//            proportional to what NMS examines, not to a full sort of all ~29 000 candidates (rocPRIM needed 7 launches).
+//   radnet_nms (generic fp64 boxes: per-class / cross-image NMS of RADNet.predict) keeps the full sort:
+//   sort     descending device radix sort of the keys (rocPRIM, header-only)
 //   nms      ONE workgroup of 1024 threads walks the sorted candidates 64 at a time:
 //            (1) 16 waves test the 64 candidates against all picks so far (picks live in LDS),
 //            (2) each wave builds rows of the 64x64 intra-chunk suppression matrix with __ballot,
@@ -30,8 +36,12 @@ struct DecodeArgs {
   double aw[32], ah[32];
 };
 
-__global__ void __launch_bounds__(256) decode_kernel(DecodeArgs g, double4* __restrict__ boxes, unsigned long long* __restrict__ keys,
-                                                     int* __restrict__ n_valid) {
+struct __attribute__((aligned(8))) IBox {      // integer-valued box (after np.round and the clip to the feature map), 8 bytes
+  short x1, y1, x2, y2;
+};
+
+__global__ void __launch_bounds__(256) decode_kernel(DecodeArgs g, double4* __restrict__ boxes, IBox* __restrict__ iboxes,
+                                                     unsigned long long* __restrict__ keys, int* __restrict__ n_valid) {
   const int hw = g.rows * g.cols;
   const int total = hw * g.a;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,13 +71,17 @@ __global__ void __launch_bounds__(256) decode_kernel(DecodeArgs g, double4* __re
   y2 = fmin((double)(g.rows - 1), y2);
   // rpn.py:163: drop where (x1 - x2 >= 0) | (y1 - y2 >= 0); NaN boxes (the reference would assert) are dropped too
   const bool ok = (x1 < x2) && (y1 < y2);
-  boxes[idx] = make_double4(x1, y1, x2, y2);
   unsigned long long key = 0ull;
-  if (ok) {
-    key = ((unsigned long long)sortable_bits(p[a]) << 32) | (unsigned int)idx;
-    atomicAdd(n_valid, 1);
-  }
+  if (ok) key = ((unsigned long long)sortable_bits(p[a]) << 32) | (unsigned int)idx;
   keys[idx] = key;
+  if (iboxes != nullptr) {          // integer path (use_regr): every coordinate is an integer in [0, 32767]
+    IBox b;
+    b.x1 = (short)x1; b.y1 = (short)y1; b.x2 = (short)x2; b.y2 = (short)y2;
+    iboxes[idx] = ok ? b : IBox{0, 0, 0, 0};
+  } else {
+    boxes[idx] = make_double4(x1, y1, x2, y2);
+    if (ok) atomicAdd(n_valid, 1);
+  }
 }
 
 __global__ void __launch_bounds__(256) nms_keys_kernel(const double* __restrict__ boxes, const float* __restrict__ probs, int n,
@@ -212,6 +226,225 @@ __global__ void __launch_bounds__(1024) nms_kernel(const unsigned long long* __r
   }
 }
 
+// ---- rpn_to_roi: select + sort + NMS in one workgroup ---------------------------------------------------------------
+constexpr int kCap = 4096;          // candidates per band (LDS: 32 KB of keys)
+constexpr int kDigitBits = 11, kDigits = 1 << kDigitBits;
+
+// rpn.py:429-447 on integer boxes: inter and union are exact integers, the comparison is the reference's
+// fl(inter / (union + 1e-6)) > thr (same margin test as `suppresses`, the division only inside the margin)
+__device__ __forceinline__ bool suppresses_int(const IBox& pk, int pk_area, const IBox& c, int c_area, double thr) {
+  const int iw = min((int)pk.x2, (int)c.x2) - max((int)pk.x1, (int)c.x1);
+  const int ih = min((int)pk.y2, (int)c.y2) - max((int)pk.y1, (int)c.y1);
+  if (iw <= 0 || ih <= 0) return false;                   // inter = 0: 0 / d > thr is false for thr > 0 (checked by the launcher)
+  const int inter_i = iw * ih;
+  const double inter = (double)inter_i, d = (double)(pk_area + c_area - inter_i) + 1e-6;
+  const double t = thr * d;
+  if (inter > t * (1.0 + 0x1p-40)) return true;
+  if (inter < t * (1.0 - 0x1p-40)) return false;
+  return inter / d > thr;
+}
+
+__global__ void __launch_bounds__(1024) select_nms_kernel(const unsigned long long* __restrict__ keys, int n, const IBox* __restrict__ iboxes,
+                                                          double thr, int max_boxes, int* __restrict__ out_count,
+                                                          long long* __restrict__ out_boxes, float* __restrict__ out_probs,
+                                                          const float* __restrict__ probs_src, int probs_stride, int probs_div) {
+  __shared__ unsigned long long skeys[kCap];
+  __shared__ unsigned int hist[kDigits];
+  __shared__ IBox pick_box[kMaxPicks];
+  __shared__ int pick_area[kMaxPicks];
+  __shared__ int pick_idx[kMaxPicks];
+  __shared__ IBox cand_box[64];
+  __shared__ int cand_area[64];
+  __shared__ int cand_idx[64];
+  __shared__ unsigned int sup[2];
+  __shared__ unsigned long long mat[64];
+  __shared__ int s_npicks, s_cnt;
+  __shared__ unsigned long long s_lo, s_prefix;
+  __shared__ int s_remaining, s_refine;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_npicks = 0;
+  unsigned long long upper = ~0ull;                 // keys >= upper have been examined (exclusive bound of the next band)
+  bool first = true;
+  __syncthreads();
+
+  while (true) {
+    // ---------------- radix select: lower bound `lo` of the best <= kCap keys below `upper`
+    if (tid == 0) { s_lo = 0ull; s_prefix = 0ull; s_remaining = kCap; s_refine = 1; }
+    __syncthreads();
+    for (int level = 0; level < 6; ++level) {
+      if (!s_refine) break;                                   // uniform: read after a barrier
+      const int hi_bit = 64 - kDigitBits * level;             // bits [hi_bit-1 : shift] are this level's digit
+      const int shift = hi_bit - kDigitBits > 0 ? hi_bit - kDigitBits : 0;
+      const int width = hi_bit - shift;                       // 11, the last level 9
+      const unsigned long long prefix = s_prefix;
+      for (int i = tid; i < kDigits; i += 1024) hist[i] = 0u;
+      __syncthreads();
+      for (int i = tid; i < n; i += 1024) {
+        const unsigned long long k = keys[i];
+        if (k != 0ull && (first || k < upper) && (level == 0 || (k >> hi_bit) == prefix)) atomicAdd(&hist[(unsigned)(k >> shift) & ((1u << width) - 1u)], 1u);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        // digits from the top: take whole digits while they fit into what is left of the band
+        const int nd = 1 << width, per = nd / 64;             // 32 (or 8) consecutive digits per lane, lane 63 holds the top ones
+        unsigned int mine = 0;
+        for (int q = 0; q < per; ++q) mine += hist[lane * per + q];
+        // suffix sum over lanes (lane L gets the count of all digits in lanes > L)
+        unsigned int above = 0;
+        for (int l = 63; l > 0; --l) {
+          const unsigned int v = __shfl(mine, l, 64);
+          if (lane < l) above += v;
+        }
+        const int remaining = s_remaining;
+        // the lane whose block contains the cut: above <= remaining < above + mine  (or the lowest lane if everything fits)
+        const bool fits_all = above + mine <= (unsigned)remaining;
+        const unsigned long long m_cut = __ballot(above <= (unsigned)remaining && !fits_all);
+        if (m_cut == 0ull) {                                  // every key of this prefix fits
+          if (lane == 0) {
+            const unsigned int total = above + mine;
+            s_remaining = remaining - (int)total;
+            s_lo = level == 0 ? 0ull : (prefix << hi_bit);     // the whole prefix
+            s_refine = 0;
+          }
+        } else {
+          const int cl = 63 - __clzll((long long)m_cut);     // highest lane that still satisfies above <= remaining: the cut lane
+          if (lane == cl) {
+            unsigned int acc = above;
+            int d = (lane + 1) * per;                          // first digit above this lane's block
+            for (int q = per - 1; q >= 0; --q) {
+              const unsigned int h = hist[lane * per + q];
+              if (acc + h > (unsigned)remaining) break;
+              acc += h;
+              d = lane * per + q;
+            }
+            // digits >= d are taken whole; digit d-1 (if any keys) is refined at the next level
+            s_remaining = remaining - (int)acc;
+            s_lo = ((level == 0 ? 0ull : (prefix << width)) | (unsigned long long)d) << shift;
+            const bool can_refine = d > 0 && shift > 0 && (remaining - (int)acc) > 0;
+            s_refine = can_refine ? 1 : 0;
+            s_prefix = (level == 0 ? 0ull : (prefix << width)) | (unsigned long long)(d - 1);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const unsigned long long lo = s_lo;
+    // ---------------- gather the band [lo, upper) into LDS
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned long long k = keys[i];
+      if (k != 0ull && k >= lo && (first || k < upper)) {
+        const int slot = atomicAdd(&s_cnt, 1);
+        if (slot < kCap) skeys[slot] = k;
+      }
+    }
+    __syncthreads();
+    const int cnt = min(s_cnt, kCap);
+    if (cnt == 0) break;                                       // nothing left below `upper`
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    for (int i = cnt + tid; i < P; i += 1024) skeys[i] = 0ull;
+    __syncthreads();
+    // ---------------- bitonic sort, descending
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P; i += 1024) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = skeys[i], b = skeys[ixj];
+            const bool desc = (i & k) == 0;
+            if (desc ? a < b : a > b) { skeys[i] = b; skeys[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---------------- greedy NMS over the band, 64 candidates at a time (all data in LDS except the box gather)
+    int pre_id = 0;
+    IBox pre_box = {0, 0, 0, 0};
+    auto fetch = [&](int base) {
+      if (tid < 64 && base + tid < cnt) {
+        pre_id = (int)(skeys[base + tid] & 0xFFFFFFFFull);
+        pre_box = iboxes[pre_id];
+      }
+    };
+    fetch(0);
+    bool full = false;
+    for (int base = 0; base < cnt; base += 64) {
+      const int nc = min(64, cnt - base);
+      if (tid < 64) {
+        if (tid < nc) {
+          cand_idx[tid] = pre_id;
+          cand_box[tid] = pre_box;
+          cand_area[tid] = ((int)pre_box.x2 - (int)pre_box.x1) * ((int)pre_box.y2 - (int)pre_box.y1);
+        }
+        if (tid < 2) sup[tid] = 0u;
+      }
+      fetch(base + 64);
+      __syncthreads();
+      const int npicks = s_npicks;
+      {
+        bool dead = false;
+        if (lane < nc) {
+          const IBox c = cand_box[lane];
+          const int ca = cand_area[lane];
+          for (int p = wave; p < npicks && !dead; p += 16) dead = suppresses_int(pick_box[p], pick_area[p], c, ca, thr);
+        }
+        const unsigned long long m = __ballot(dead);
+        if (lane == 0 && m) {
+          atomicOr(&sup[0], (unsigned int)(m & 0xFFFFFFFFull));
+          atomicOr(&sup[1], (unsigned int)(m >> 32));
+        }
+      }
+      for (int j = wave; j < 64; j += 16) {
+        bool hit = false;
+        if (j < nc && lane < nc && lane > j) hit = suppresses_int(cand_box[j], cand_area[j], cand_box[lane], cand_area[lane], thr);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) mat[j] = m;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long alive = ~(((unsigned long long)sup[1] << 32) | sup[0]);
+        if (nc < 64) alive &= (1ull << nc) - 1ull;
+        int np = npicks;
+        while (alive != 0ull && np < max_boxes) {
+          const int j = __ffsll((long long)alive) - 1;
+          pick_box[np] = cand_box[j];
+          pick_area[np] = cand_area[j];
+          pick_idx[np] = cand_idx[j];
+          ++np;
+          alive &= ~mat[j];
+          alive &= ~(1ull << j);
+        }
+        s_npicks = np;
+      }
+      __syncthreads();
+      if (s_npicks >= max_boxes) { full = true; break; }
+    }
+    if (full || lo == 0ull) break;                             // lo == 0: the band reached down to the smallest key
+    upper = lo;
+    first = false;
+    __syncthreads();
+  }
+  __syncthreads();
+  const int np = s_npicks;
+  if (tid == 0) *out_count = np;
+  for (int i = tid; i < np; i += blockDim.x) {
+    const IBox b = pick_box[i];
+    out_boxes[4 * i + 0] = (long long)b.x1;
+    out_boxes[4 * i + 1] = (long long)b.y1;
+    out_boxes[4 * i + 2] = (long long)b.x2;
+    out_boxes[4 * i + 3] = (long long)b.y2;
+    if (out_probs) {
+      const int id = pick_idx[i];
+      const int a = id / probs_div, pix = id - a * probs_div;
+      out_probs[i] = probs_src[(size_t)pix * probs_stride + a];
+    }
+  }
+}
+
 struct WsLayout {
   unsigned long long* keys_in;
   unsigned long long* keys_out;
@@ -263,8 +496,18 @@ extern "C" int radnet_rpn_to_roi(radnet_ctx* ctx, const float* pred, int32_t ld_
   DecodeArgs g{};
   g.pred = pred; g.ld = ld_pred; g.rows = rows; g.cols = cols; g.a = a; g.std_scaling = std_scaling; g.use_regr = use_regr;
   for (int i = 0; i < a; ++i) { g.aw[i] = anchor_wh_host[2 * i]; g.ah[i] = anchor_wh_host[2 * i + 1]; }
+  // hot path (use_regr: integer boxes; rows, cols < 32768; thr > 0): decode + ONE select / sort / NMS workgroup
+  if (use_regr && rows < 32768 && cols < 32768 && overlap_thresh > 0.0 && getenv("RADNET_PROPOSALS_ROCPRIM") == nullptr) {
+    IBox* ib = reinterpret_cast<IBox*>(L.boxes);          // the fp64 box area of the workspace holds the packed boxes instead
+    hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, (double4*)nullptr, ib, L.keys_in, (int*)nullptr);
+    RADNET_CHECK_LAUNCH(ctx, "decode");
+    hipLaunchKernelGGL(select_nms_kernel, dim3(1), dim3(1024), 0, ctx->stream, L.keys_in, (int)n, ib, overlap_thresh, max_boxes, out_count,
+                       (long long*)out_boxes, out_probs, pred, ld_pred, rows * cols);
+    RADNET_CHECK_LAUNCH(ctx, "select_nms");
+    return RADNET_OK;
+  }
   RADNET_CHECK_HIP(ctx, hipMemsetAsync(L.counters, 0, 256, ctx->stream));
-  hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, L.boxes, L.keys_in, L.counters);
+  hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, L.boxes, (IBox*)nullptr, L.keys_in, L.counters);
   RADNET_CHECK_LAUNCH(ctx, "decode");
   int rc = sort_desc(ctx, L, n);
   if (rc != RADNET_OK) return rc;

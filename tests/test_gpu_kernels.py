@@ -567,3 +567,69 @@ def test_head_tail_fused_equals_separate_kernels(ctx, groups, idle):
     ctx.call("radnet_head_tail_bwd", feat1, dz1, d["y5"], R, hw, c, d["w"], ld, nc + nreg, dw1, db1, df1, gl1, 1)
     ctx.sync()
     close(dw1.cpu().numpy(), 2 * dw0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def _rpn_to_roi(ctx, pred, rows, cols, A, awh, thr, mb, rocprim):
+    import os
+    R = torch.zeros(mb, 4, dtype=torch.int64, device="cuda"); Rp = torch.zeros(mb, device="cuda"); Rn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(rows * cols * A)), dtype=torch.uint8, device="cuda")
+    predd = dev(pred)
+    if rocprim:
+        os.environ["RADNET_PROPOSALS_ROCPRIM"] = "1"
+    else:
+        os.environ.pop("RADNET_PROPOSALS_ROCPRIM", None)
+    try:
+        rc = ctx.lib.radnet_rpn_to_roi(ctx.h, predd.data_ptr(), 64, rows, cols, A, awh.ctypes.data_as(C.POINTER(C.c_double)), 4.0, 1, float(thr), mb,
+                                       R.data_ptr(), Rp.data_ptr(), Rn.data_ptr(), ws.data_ptr())
+    finally:
+        os.environ.pop("RADNET_PROPOSALS_ROCPRIM", None)
+    ctx.check(rc, "rpn_to_roi")
+    ctx.sync()
+    n = int(Rn.cpu()[0])
+    return R.cpu().numpy()[:n], Rp.cpu().numpy()[:n]
+
+
+PROPOSAL_STRESS = [  # rows, cols, A, score kind, regr sigma, thr, max_boxes
+    (38, 63, 12, "distinct", 0.5, 0.7, 300),
+    (38, 63, 12, "saturated", 0.5, 0.7, 300),      # thousands of scores exactly 1.0: the radix select must cut inside a tie (index digits)
+    (38, 63, 12, "few_levels", 0.5, 0.7, 300),     # 5 distinct score values
+    (38, 63, 12, "distinct", 0.05, 0.95, 1000),    # picks never reach max_boxes: every band is examined (7 bands)
+    (63, 63, 12, "distinct", 0.3, 0.7, 300),       # 47 628 candidates
+    (63, 63, 12, "saturated", 1.5, 0.5, 300),
+    (10, 12, 9, "distinct", 0.5, 0.9, 300),        # fewer candidates than one band
+    (2, 3, 12, "saturated", 0.2, 0.7, 300),
+    (38, 63, 12, "tiny", 0.5, 0.7, 300),           # scores ~1e-30 .. 1e-20: exponent digits decide
+]
+
+
+@pytest.mark.parametrize("case", PROPOSAL_STRESS, ids=["%dx%dx%d_%s_thr%s_max%d" % (c[0], c[1], c[2], c[3], c[5], c[6]) for c in PROPOSAL_STRESS])
+def test_select_nms_kernel_matches_reference_and_full_sort(ctx, case):
+    """radnet_rpn_to_roi's one-workgroup radix-select + LDS sort + integer NMS against (a) the oracle's rpn_to_roi (pinned by
+    the reference's own outputs) where scores are tie-free, and (b) the former full-sort path (rocPRIM + fp64 NMS, kept behind
+    RADNET_PROPOSALS_ROCPRIM=1) on adversarial score distributions -- same order rule among equal scores, so bit-identical."""
+    from faster_rcnn.config import Config
+    from oracle import glue
+    rows, cols, A, kind, sig, thr, mb = case
+    rs = np.random.RandomState(rows * 131 + cols + A + len(kind))
+    n = rows * cols * A
+    if kind == "distinct":
+        cls = (rs.permutation(n).astype(np.float32) / np.float32(n))
+    elif kind == "saturated":
+        cls = np.where(rs.uniform(size=n) < 0.4, np.float32(1.0), rs.uniform(0.0, 1.0, n).astype(np.float32)).astype(np.float32)
+    elif kind == "few_levels":
+        cls = rs.choice(np.array([0.1, 0.25, 0.5, 0.75, 0.999], np.float32), n)
+    else:
+        cls = (10.0 ** rs.uniform(-30, -20, n)).astype(np.float32)
+    regr = (rs.standard_normal((rows * cols, 4 * A)) * sig * 4.0).astype(np.float32)
+    pred = np.zeros((rows * cols, 64), np.float32)
+    pred[:, :A] = cls.reshape(rows * cols, A); pred[:, A:5 * A] = regr
+    Cc = Config()
+    if A == 9:
+        Cc.anchor_box_scales = [128, 256, 512]
+    awh = np.array([[(s * r[0]) / 16, (s * r[1]) / 16] for s in Cc.anchor_box_scales for r in Cc.anchor_box_ratios], dtype=np.float64)
+    R_new, P_new = _rpn_to_roi(ctx, pred, rows, cols, A, awh, thr, mb, rocprim=False)
+    R_old, P_old = _rpn_to_roi(ctx, pred, rows, cols, A, awh, thr, mb, rocprim=True)
+    assert R_new.shape == R_old.shape and np.array_equal(R_new, R_old) and np.array_equal(P_new, P_old)
+    if kind in ("distinct", "tiny") and len(np.unique(cls)) == n:
+        ref = glue.rpn_to_roi(pred[:, :A].reshape(1, rows, cols, A), pred[:, A:5 * A].reshape(1, rows, cols, 4 * A), Cc, True, mb, thr)
+        assert np.array_equal(R_new, ref)
