@@ -4,14 +4,11 @@
 //
 //   decode   one thread per anchor (a,row,col): delta decode, round-half-even, clamp, clip, validity;
 //            emits a 64-bit sort key (order-preserving score bits << 32 | flat index), 0 for dropped boxes.
-//   rpn_to_roi (the hot path; coordinates are integers after np.round + clip): ONE launch of ONE workgroup does the rest --
-//            select_nms_kernel: a radix SELECT over the keys (11-bit digits, histogram in LDS) finds the lower bound of the best
-//            <= 4096 not yet examined, those keys are gathered into LDS, bitonic-sorted there (descending = "stable ascending,
-//            walk from the end": among equal scores the higher flat index first) and fed to the greedy NMS below with exact
-//            INTEGER intersection / union arithmetic; if 300 picks are not reached the next band follows.  Work is
-//            proportional to what NMS examines, not to a full sort of all ~29 000 candidates (rocPRIM needed 7 launches).
-//   radnet_nms (generic fp64 boxes: per-class / cross-image NMS of RADNet.predict) keeps the full sort:
-//   sort     descending device radix sort of the keys (rocPRIM, header-only)
+//   sort     descending device radix sort of the keys (rocPRIM, header-only) -> "stable ascending,
+//            walk from the end": among equal scores the higher flat index comes first.
+//   (alternative for rpn_to_roi, RADNET_PROPOSALS_SELECT=1: select_nms_kernel -- one workgroup: radix SELECT of the best
+//    <= 4096 unexamined keys (11-bit digits, histogram in LDS), LDS bitonic sort, integer-arithmetic NMS, band by band;
+//    bit-identical, measured slower than the full sort: see radnet_rpn_to_roi)
 //   nms      ONE workgroup of 1024 threads walks the sorted candidates 64 at a time:
 //            (1) 16 waves test the 64 candidates against all picks so far (picks live in LDS),
 //            (2) each wave builds rows of the 64x64 intra-chunk suppression matrix with __ballot,
@@ -280,9 +277,31 @@ __global__ void __launch_bounds__(1024) select_nms_kernel(const unsigned long lo
       const unsigned long long prefix = s_prefix;
       for (int i = tid; i < kDigits; i += 1024) hist[i] = 0u;
       __syncthreads();
-      for (int i = tid; i < n; i += 1024) {
-        const unsigned long long k = keys[i];
-        if (k != 0ull && (first || k < upper) && (level == 0 || (k >> hi_bit) == prefix)) atomicAdd(&hist[(unsigned)(k >> shift) & ((1u << width) - 1u)], 1u);
+      // 8 independent loads in flight per thread: one memory round trip per 8192 keys instead of one per 1024
+      for (int i0 = tid; i0 < n; i0 += 8 * 1024) {
+        unsigned long long kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = i0 + u * 1024 < n ? keys[i0 + u * 1024] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned long long k = kk[u];
+          bool todo = k != 0ull && (first || k < upper) && (level == 0 || (k >> hi_bit) == prefix);
+          const unsigned digit = (unsigned)(k >> shift) & ((1u << width) - 1u);
+          // Scores cluster (the coarse digits of most keys are equal): 64 lanes adding to ONE LDS word serialise.  Up to four
+          // rounds of "the first pending lane's digit: one add of the number of lanes that share it", the rest lane by lane.
+#pragma unroll 1
+          for (int round = 0; round < 4; ++round) {
+            const unsigned long long pend = __ballot(todo);
+            if (pend == 0ull) break;
+            const unsigned d0 = (unsigned)__shfl((int)digit, __ffsll((long long)pend) - 1, 64);
+            const unsigned long long same = __ballot(todo && digit == d0);
+            if (todo && digit == d0) {
+              if ((unsigned)lane == (unsigned)(__ffsll((long long)same) - 1)) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+              todo = false;
+            }
+          }
+          if (todo) atomicAdd(&hist[digit], 1u);
+        }
       }
       __syncthreads();
       if (wave == 0) {
@@ -333,11 +352,22 @@ __global__ void __launch_bounds__(1024) select_nms_kernel(const unsigned long lo
     // ---------------- gather the band [lo, upper) into LDS
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-      const unsigned long long k = keys[i];
-      if (k != 0ull && k >= lo && (first || k < upper)) {
-        const int slot = atomicAdd(&s_cnt, 1);
-        if (slot < kCap) skeys[slot] = k;
+    for (int i0 = tid; i0 < n; i0 += 8 * 1024) {
+      unsigned long long kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kk[u] = i0 + u * 1024 < n ? keys[i0 + u * 1024] : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long k = kk[u];
+        const bool take = k != 0ull && k >= lo && (first || k < upper);
+        const unsigned long long m = __ballot(take);            // one counter update per wave, slots by rank inside the wave
+        if (m != 0ull) {
+          int base = 0;
+          if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&s_cnt, __popcll(m));
+          base = __shfl(base, __ffsll((long long)m) - 1, 64);
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (take && slot < kCap) skeys[slot] = k;
+        }
       }
     }
     __syncthreads();
@@ -496,8 +526,13 @@ extern "C" int radnet_rpn_to_roi(radnet_ctx* ctx, const float* pred, int32_t ld_
   DecodeArgs g{};
   g.pred = pred; g.ld = ld_pred; g.rows = rows; g.cols = cols; g.a = a; g.std_scaling = std_scaling; g.use_regr = use_regr;
   for (int i = 0; i < a; ++i) { g.aw[i] = anchor_wh_host[2 * i]; g.ah[i] = anchor_wh_host[2 * i + 1]; }
-  // hot path (use_regr: integer boxes; rows, cols < 32768; thr > 0): decode + ONE select / sort / NMS workgroup
-  if (use_regr && rows < 32768 && cols < 32768 && overlap_thresh > 0.0 && getenv("RADNET_PROPOSALS_ROCPRIM") == nullptr) {
+  // Alternative path, RADNET_PROPOSALS_SELECT=1 (use_regr: integer boxes; rows, cols < 32768; thr > 0): decode + ONE workgroup
+  // that selects, sorts and suppresses band by band -- 2 launches instead of 10 and no vendor sort, bit-identical results
+  // (tests/test_gpu_kernels.py), but measured SLOWER alone on the chip at 1000x600 (28 728 candidates, 300 picks after ~2 400
+  // examined): radix select 78 us + LDS bitonic sort of 4 096 keys 67 us against rocPRIM's 45 us for the full sort, and the
+  // greedy scan itself -- 38 chunks of 64 candidates at ~5 us, three barriers and a serial resolve each -- costs the same
+  // ~200 us with integer arithmetic as with fp64 (it is latency-, not arithmetic-bound).  So the full sort stays the default.
+  if (use_regr && rows < 32768 && cols < 32768 && overlap_thresh > 0.0 && getenv("RADNET_PROPOSALS_SELECT") != nullptr) {
     IBox* ib = reinterpret_cast<IBox*>(L.boxes);          // the fp64 box area of the workspace holds the packed boxes instead
     hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, (double4*)nullptr, ib, L.keys_in, (int*)nullptr);
     RADNET_CHECK_LAUNCH(ctx, "decode");

@@ -575,14 +575,14 @@ def _rpn_to_roi(ctx, pred, rows, cols, A, awh, thr, mb, rocprim):
     ws = torch.empty(int(ctx.lib.radnet_proposals_ws_bytes(rows * cols * A)), dtype=torch.uint8, device="cuda")
     predd = dev(pred)
     if rocprim:
-        os.environ["RADNET_PROPOSALS_ROCPRIM"] = "1"
+        os.environ.pop("RADNET_PROPOSALS_SELECT", None)
     else:
-        os.environ.pop("RADNET_PROPOSALS_ROCPRIM", None)
+        os.environ["RADNET_PROPOSALS_SELECT"] = "1"
     try:
         rc = ctx.lib.radnet_rpn_to_roi(ctx.h, predd.data_ptr(), 64, rows, cols, A, awh.ctypes.data_as(C.POINTER(C.c_double)), 4.0, 1, float(thr), mb,
                                        R.data_ptr(), Rp.data_ptr(), Rn.data_ptr(), ws.data_ptr())
     finally:
-        os.environ.pop("RADNET_PROPOSALS_ROCPRIM", None)
+        os.environ.pop("RADNET_PROPOSALS_SELECT", None)
     ctx.check(rc, "rpn_to_roi")
     ctx.sync()
     n = int(Rn.cpu()[0])
@@ -604,9 +604,10 @@ PROPOSAL_STRESS = [  # rows, cols, A, score kind, regr sigma, thr, max_boxes
 
 @pytest.mark.parametrize("case", PROPOSAL_STRESS, ids=["%dx%dx%d_%s_thr%s_max%d" % (c[0], c[1], c[2], c[3], c[5], c[6]) for c in PROPOSAL_STRESS])
 def test_select_nms_kernel_matches_reference_and_full_sort(ctx, case):
-    """radnet_rpn_to_roi's one-workgroup radix-select + LDS sort + integer NMS against (a) the oracle's rpn_to_roi (pinned by
-    the reference's own outputs) where scores are tie-free, and (b) the former full-sort path (rocPRIM + fp64 NMS, kept behind
-    RADNET_PROPOSALS_ROCPRIM=1) on adversarial score distributions -- same order rule among equal scores, so bit-identical."""
+    """radnet_rpn_to_roi's alternative one-workgroup path (RADNET_PROPOSALS_SELECT=1: radix select + LDS sort + integer NMS)
+    against (a) the oracle's rpn_to_roi (pinned by the reference's own outputs) where scores are tie-free, and (b) the default
+    full-sort path (rocPRIM + fp64 NMS) on adversarial score distributions -- same order rule among equal scores, so the two
+    must agree bit for bit."""
     from faster_rcnn.config import Config
     from oracle import glue
     rows, cols, A, kind, sig, thr, mb = case
