@@ -163,18 +163,15 @@ int radnet_dense_heads_fwd(radnet_ctx* ctx, const float* feat, int32_t r, int32_
 int radnet_dense_heads_bwd(radnet_ctx* ctx, const float* feat, const float* dz, int32_t r, int32_t k, const float* w,
                            int32_t ldw, int32_t nout, float* dw, float* db, float* dfeat, int32_t accumulate);
 
-/* The tail of classifier_layer and its losses in two launches (csrc/head_tail.hip): avg-pool + both dense heads (+ softmax)
- * per RoI and -- with targets (y1 != 0) -- losses.py:69-95 and dz in the same launch; then dense backward + avg-pool backward
- * with res5c's ReLU mask.  The r RoIs come in `groups` equal groups, each its own reference step (own normalisers; losses
+/* The tail of classifier_layer and its losses in one launch (csrc/head_tail.hip): avg-pool + both dense heads (+ softmax)
+ * per RoI and -- with targets (y1 != 0) -- losses.py:69-95 and dz in the same launch.  The r RoIs come in `groups` equal groups, each its own reference step (own normalisers; losses
  * [groups][3] = cls, regr, accuracy); group_live[g] == 0: zero gradient rows, losses untouched.  scratch: device memory of
- * radnet_head_tail_scratch_bytes(r) bytes whose first 256 bytes the caller zeroed once. */
+ * radnet_head_tail_scratch_bytes(r) bytes the caller zeroed ONCE (arrival counters that every launch leaves at zero, the
+ * channel slices' partial sums, per-RoI loss terms). */
 uint64_t radnet_head_tail_scratch_bytes(int32_t r);
 int radnet_head_tail_fwd(radnet_ctx* ctx, const float* y5, int32_t r, int32_t hw, int32_t c, const float* w, int32_t ldw, const float* b,
                          int32_t nc, int32_t nreg, float* feat, float* p_cls, float* p_regr, const float* y1, const float* y2,
                          float* dz, float* losses, int32_t groups, const int32_t* group_live, void* scratch);
-int radnet_head_tail_bwd(radnet_ctx* ctx, const float* feat, const float* dz, const float* y5, int32_t r, int32_t hw, int32_t c,
-                         const float* w, int32_t ldw, int32_t nout, float* dw, float* db, float* dfeat, float* g_last,
-                         int32_t accumulate);
 
 /* ---- losses (losses.py) ----------------------------------------------------------------------
  * RPN (losses.py:16-66): pred [m][ld_pred] holds the sigmoid class scores in columns [0,A) and the
@@ -315,6 +312,7 @@ typedef struct radnet_head_desc {
   const float* y5; int32_t hw, feat_c; float* feat;
   const float* dense_w; int32_t dense_ld; const float* dense_b; int32_t nc, nreg;
   float* p_cls; float* p_regr;
+  void* tail_scratch;      /* radnet_head_tail_scratch_bytes(n_rois) bytes, zeroed once by the caller */
 } radnet_head_desc;
 
 /* One tile of RADNet.predict up to the classifier outputs (RADNet.py:520-600): preprocess (img_u8 != 0: uint8 BGR [h][w][3]
@@ -377,7 +375,7 @@ typedef struct radnet_train_desc {
   float* head_dz; float* det_losses; float* dense_dw; float* dense_db; float* dfeat; float* g_last;
   const radnet_op* head_bwd_ops; int32_t n_head_bwd;
   float* head_shift; const float* head_scale; const float* head_bias; const float* head_t0; int64_t head_bias_len;
-  void* tail_scratch;      /* radnet_head_tail_scratch_bytes(head->n_rois) bytes, first 256 zeroed once */
+  void* tail_scratch;      /* unused (the head descriptor carries the scratch); kept for layout stability */
 } radnet_train_desc;
 int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, const radnet_host_hooks* hooks, float* losses5,
                       int32_t* took_head_step);

@@ -127,12 +127,12 @@ __global__ void rois_xywh_kernel(const long long* __restrict__ R, const int* __r
 
 // classifier_layer forward; with targets (y1 != 0) the detector losses and dz come out of the tail's launch (head_tail.hip)
 int head_forward(radnet_ctx* ctx, const radnet_head_desc& h, const float* y1 = nullptr, const float* y2 = nullptr, float* dz = nullptr,
-                 float* losses = nullptr, void* scratch = nullptr) {
+                 float* losses = nullptr) {
   int rc = radnet_roi_resize_fwd(ctx, h.fmap, h.fh, h.fw, h.fc, h.rois, h.n_rois, h.pool, h.pooled);
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, h.fwd_ops, h.n_fwd);
   if (rc == RADNET_OK)
     rc = radnet_head_tail_fwd(ctx, h.y5, h.n_rois, h.hw, h.feat_c, h.dense_w, h.dense_ld, h.dense_b, h.nc, h.nreg, h.feat, h.p_cls, h.p_regr, y1,
-                              y2, dz, losses, 1, nullptr, scratch);
+                              y2, dz, losses, 1, nullptr, h.tail_scratch);
   return rc;
 }
 
@@ -215,10 +215,10 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   RADNET_CHECK_HIP(ctx, hipMemcpyAsync(d->sel, d->h_sel, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, st));
   rc = radnet_roi_batch_pack(ctx, d->sel, k, d->roi_cls, d->roi_box, d->roi_t, h.nc, d->bg_class, const_cast<float*>(h.rois), d->y1, d->y2);
   // ---- model_classifier.train_on_batch (train.py:393)
-  if (rc == RADNET_OK) rc = head_forward(ctx, h, d->y1, d->y2, d->head_dz, d->det_losses, d->tail_scratch);
+  if (rc == RADNET_OK) rc = head_forward(ctx, h, d->y1, d->y2, d->head_dz, d->det_losses);
   if (rc == RADNET_OK)
-    rc = radnet_head_tail_bwd(ctx, h.feat, d->head_dz, h.y5, h.n_rois, h.hw, h.feat_c, h.dense_w, h.dense_ld, h.nc + h.nreg, d->dense_dw,
-                              d->dense_db, d->dfeat, d->g_last, 1);
+    rc = radnet_dense_heads_bwd(ctx, h.feat, d->head_dz, h.n_rois, h.feat_c, h.dense_w, h.dense_ld, h.nc + h.nreg, d->dense_dw, d->dense_db, d->dfeat, 1);
+  if (rc == RADNET_OK) rc = radnet_avgpool_bwd_relu(ctx, d->dfeat, h.y5, h.n_rois, h.hw, h.feat_c, d->g_last);
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, d->head_bwd_ops, d->n_head_bwd);
   if (rc == RADNET_OK && d->world > 1) rc = radnet_allreduce_grads(ctx, d->head_opt.g, d->head_opt.n);
   if (rc == RADNET_OK)

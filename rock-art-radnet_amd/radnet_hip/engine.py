@@ -153,7 +153,7 @@ class FasterRCNNEngine:
         self._graphs = {}
         self._compiled = {}
         self.use_graphs = os.environ.get("RADNET_NO_GRAPHS", "0") != "1"
-        # classifier tail (avg-pool, dense heads, detector losses and their backward) as two launches instead of five
+        # classifier tail (avg-pool, dense heads, detector losses) as one launch instead of three
         self.fuse_tail = os.environ.get("RADNET_NO_TAIL_FUSION", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
@@ -865,9 +865,11 @@ class FasterRCNNEngine:
         feat = buf(R, 2048)
         pcls, pregr = buf(R, self.nc), buf(R, self.nreg)
         y1, y2 = buf(R, self.nc), buf(R, 2 * self.nreg)
+        tail_scratch = torch.zeros(int(self.lib.radnet_head_tail_scratch_bytes(R)), dtype=torch.uint8, device=dev)
+        keep.append(tail_scratch)
         if not training:
             plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls, pregr=pregr,
-                        F=F, fh=fh, fw=fw, keep=keep, groups=groups)
+                        F=F, fh=fh, fw=fw, keep=keep, groups=groups, tail_scratch=tail_scratch)
             self._plans[key] = plan
             return plan
         dz = buf(R, self.nc + self.nreg)
@@ -921,9 +923,8 @@ class FasterRCNNEngine:
             raise RuntimeError("head gradient buckets do not tile the kernel part of the arena: %r" % (cover,))
         if [sl for _, sl in bwd_parts] != self.head_exchange_slices():
             raise RuntimeError("head backward parts and head_exchange_slices() disagree")
-        tail_scratch = torch.zeros(int(self.lib.radnet_head_tail_scratch_bytes(R)), dtype=torch.uint8, device=dev)
         live = torch.ones(groups, dtype=torch.int32, device=dev)
-        keep += [tail_scratch, live]
+        keep.append(live)
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
                     tail_scratch=tail_scratch, live=live, live_host=[1] * groups,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep, groups=groups)
@@ -967,7 +968,7 @@ class FasterRCNNEngine:
         self._run(hp["fwd"])
         hp["_tail_fused"] = False
         if self.fuse_tail:
-            fused_loss = training and loss_out is not None and "tail_scratch" in hp
+            fused_loss = training and loss_out is not None and "live" in hp
             if fused_loss:
                 flags = [1] * G if group_live is None else [1 if f else 0 for f in group_live]
                 if flags != hp["live_host"]:
@@ -976,7 +977,7 @@ class FasterRCNNEngine:
             self.ctx.call("radnet_head_tail_fwd", hp["y5"], hp["R"], hp["hw"], 2048, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                           hp["feat"], hp["pcls"], hp["pregr"], hp["y1"] if fused_loss else None, hp["y2"] if fused_loss else None,
                           hp["dz"] if fused_loss else None, loss_out if fused_loss else None, G, hp["live"] if fused_loss else None,
-                          hp["tail_scratch"] if fused_loss else None)
+                          hp["tail_scratch"])
             hp["_tail_fused"] = fused_loss
             return
         self.ctx.call("radnet_avgpool_fwd", hp["y5"], hp["R"], hp["hw"], 2048, hp["feat"])
@@ -1006,13 +1007,9 @@ class FasterRCNNEngine:
                     continue
                 self.ctx.call("radnet_det_loss", hp["pcls"][g * rg:], hp["pregr"][g * rg:], hp["y1"][g * rg:], hp["y2"][g * rg:], rg, self.nc,
                               self.nreg, hp["dz"][g * rg:], lo)
-        if self.fuse_tail and "tail_scratch" in hp:
-            self.ctx.call("radnet_head_tail_bwd", hp["feat"], hp["dz"], hp["y5"], hp["R"], hp["hw"], 2048, self.dense_w, self.dense_ld,
-                          self.nc + self.nreg, self.dense_dw, self.dense_db, hp["dfeat"], hp["g_last"], 1 if accumulate else 0)
-        else:
-            self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
-                          self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
-            self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
+        self.ctx.call("radnet_dense_heads_bwd", hp["feat"], hp["dz"], hp["R"], 2048, self.dense_w, self.dense_ld, self.nc + self.nreg,
+                      self.dense_dw, self.dense_db, hp["dfeat"], 1 if accumulate else 0)
+        self.ctx.call("radnet_avgpool_bwd_relu", hp["dfeat"], hp["y5"], hp["R"], hp["hw"], 2048, hp["g_last"])
         if on_part is None or "bwd_parts" not in hp:
             self._run(hp["bwd"])
             return

@@ -56,7 +56,7 @@ class HeadDesc(C.Structure):
                 ("fwd_ops", C.POINTER(Op)), ("n_fwd", C.c_int32),
                 ("y5", C.c_void_p), ("hw", C.c_int32), ("feat_c", C.c_int32), ("feat", C.c_void_p),
                 ("dense_w", C.c_void_p), ("dense_ld", C.c_int32), ("dense_b", C.c_void_p), ("nc", C.c_int32), ("nreg", C.c_int32),
-                ("p_cls", C.c_void_p), ("p_regr", C.c_void_p)]
+                ("p_cls", C.c_void_p), ("p_regr", C.c_void_p), ("tail_scratch", C.c_void_p)]
 
 
 class TileDesc(C.Structure):
@@ -169,7 +169,6 @@ def load_library():
         "radnet_dense_heads_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32]),
         "radnet_head_tail_scratch_bytes": (u64, [i32]),
         "radnet_head_tail_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
-        "radnet_head_tail_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32]),
         "radnet_rpn_loss": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
         "radnet_det_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32]),

@@ -36,6 +36,7 @@ def _head_desc(eng, hp):
     h.y5, h.hw, h.feat_c, h.feat = hp["y5"].data_ptr(), hp["hw"], 2048, hp["feat"].data_ptr()
     h.dense_w, h.dense_ld, h.dense_b, h.nc, h.nreg = eng.dense_w.data_ptr(), eng.dense_ld, eng.dense_b.data_ptr(), eng.nc, eng.nreg
     h.p_cls, h.p_regr = hp["pcls"].data_ptr(), hp["pregr"].data_ptr()
+    h.tail_scratch = hp["tail_scratch"].data_ptr()
     return h
 
 

@@ -277,3 +277,36 @@ def test_cfg4_per_gpu_batch_2_at_1000x600_one_program_vs_oracle():
             d_ref, d_gpu = ot.P[name][k] - P[name][k], w_after[name][k] - P[name][k]
             big = np.abs(d_ref) > 0.9 * 5e-5                               # first Adam step: |delta| ~ lr where the gradient is not tiny
             assert big.sum() > 0 and np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, k)
+
+
+def test_cfg3_predict_tile_2048_at_img_size_1000_rpn_and_proposals_vs_oracle():
+    """BASELINE.md 3 also names img_size = 1000 for cfg 3 (1000x1000 network input, 63x63 map, 47 628 anchors): device resize
+    bit-exact, RPN activations against the oracle, proposals bit-exact on the device's tensors, and one 20-RoI classifier
+    chunk against the oracle (the 300-RoI single pass is covered at img_size = 600 above)."""
+    from faster_rcnn import models as M
+    from faster_rcnn import rpn
+    from faster_rcnn.RADNet import RADNet, resize_cubic
+    from faster_rcnn.base_models import resnet50
+    from faster_rcnn.config import Config
+    from oracle import dense, glue, resize as oresize, step as ostep
+    C = Config()
+    C.img_size = 1000
+    P = dense.init_params(seed=3)
+    m_rpn, m_cls, m_all, m_rpn3, m_det = M.build_models(C, weights=copy.deepcopy(P))
+    tile = np.random.RandomState(4).randint(0, 256, (2048, 2048, 3)).astype(np.uint8)
+    net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+    small = resize_cubic(tile, 1000, 1000)
+    assert np.array_equal(small, oresize.resize_bicubic_u8(tile, 1000, 1000))
+    X, ratio = net.format_img(tile)
+    assert X.shape == (1, 1000, 1000, 3)
+    Y1, Y2, F = m_rpn3.predict(X)
+    p, r, F_ref = ostep.rpn_only_forward(P, small)
+    assert F.shape == F_ref.shape == (1, 63, 63, 1024)
+    assert rel_err(F, F_ref) < 1e-3 and rel_err(Y1, p) < 1e-3 and rel_err(Y2, r) < 1e-3
+    R = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
+    assert np.array_equal(R, glue.rpn_to_roi(Y1, Y2, C, True, 300, 0.7))
+    Rx = R[:20].copy()
+    Rx[:, 2] -= Rx[:, 0]; Rx[:, 3] -= Rx[:, 1]
+    pc, pr = m_det.predict([F, Rx[None]])
+    rc, rr, _ = dense.head_forward(P, F, Rx.astype(np.float32), 7)
+    assert np.abs(pc - rc).max() < 2e-3 and np.abs(pr - rr).max() < 2e-3 * max(1.0, np.abs(rr).max())

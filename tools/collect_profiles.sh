@@ -1,5 +1,5 @@
 set -e
-TAG=${TAG:-v11}
+TAG=${TAG:-r02}
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=gpurun_out/$TAG/tune.txt
@@ -19,5 +19,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/$TAG/pmc3 -o p --output-
 python tools/pmc_summary.py gpurun_out/$TAG/pmc1 gpurun_out/$TAG/pmc2 gpurun_out/$TAG/pmc3 > gpurun_out/$TAG/pmc_summary.txt
 # keep the merge small
 rm -f gpurun_out/$TAG/pmc*/p_counter_collection.csv gpurun_out/$TAG/pmc*/p_kernel_trace.csv gpurun_out/$TAG/pipe/pipe_kernel_trace.csv gpurun_out/$TAG/serial/serial_kernel_trace.csv
+# secondary measurements: per-GPU batch 2 as one program (BASELINE cfg 4 on one GPU), proposal paths, Winograd vs direct
+unset RADNET_SIDE_PREFETCH
+python bench.py --tune-cache gpurun_out/$TAG/tune_b2.txt --per-gpu-batch 2 --steps 150 --warmup 20 --no-cpu-baseline > gpurun_out/$TAG/bench_batch2.json 2> gpurun_out/$TAG/bench_batch2.err
+python tools/proposals_timing.py > gpurun_out/$TAG/proposals_timing.txt 2>&1
+python tools/winograd_timing.py > gpurun_out/$TAG/winograd_timing.txt 2>&1
+python tools/host_timeline.py 200 > gpurun_out/$TAG/host_timeline.txt 2>&1
 ls -la gpurun_out/$TAG gpurun_out/$TAG/serial | head -40
 head -5 gpurun_out/$TAG/lanes.txt; head -12 gpurun_out/$TAG/trace_summary.txt; head -12 gpurun_out/$TAG/pmc_summary.txt
