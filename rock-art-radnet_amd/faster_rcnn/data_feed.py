@@ -12,8 +12,9 @@ Same control flow and the same draws from the random stream as the reference, in
 Augmentation (augmentation.py:85-533): the three exact geometric ones are built -- horizontal / vertical
 flip, rotation by 90 / 180 / 270 degrees (augmentation.py:85-159; array reversals and transposes, so no interpolation is
 involved), with the reference's draws (np.random.random() < 0.5 per enabled switch, in its order; np.random.choice over
-the angle).  Arbitrary rotation, shear, brightness and noise need OpenCV / scikit-image semantics that cannot be pinned
-here: in train mode those switches must be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
+the angle), and the brightness shift (augmentation.py:303-333: pure NumPy in the reference, pinned by the reference's own
+outputs -- tests/golden/brightness.npz).  Arbitrary rotation, shear and the noise / contrast family need OpenCV /
+scikit-image semantics that cannot be pinned here: in train mode those switches must be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
 HWC`): OpenCV, which the reference decodes with, is not part of this build.
 
 rng: None = NumPy's global stream, i.e. exactly the reference's interleaving with the step's own draws when samples are
@@ -30,7 +31,28 @@ from .utils import get_new_img_size
 
 AUGMENT_SWITCHES = ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear",
                     "use_brightness", "use_noise")          # augmentation.py:495-518
-EXACT_AUGMENTATIONS = AUGMENT_SWITCHES[:3]
+EXACT_AUGMENTATIONS = AUGMENT_SWITCHES[:3] + ("use_brightness",)
+
+
+def brightness(img, rng=np.random):
+    """augmentation.brightness (augmentation.py:303-333): pixels that are exactly 0 (in a channel) are background and stay 0;
+    the rest moves darker with probability p = (mean - 75) / 105 by U[0,1) * (mean - 75), else lighter by U[0,1) *
+    (180 - mean), in float32, clipped to [0, 255] and truncated to uint8.  Images whose foreground mean is outside (75, 180)
+    are returned unchanged WITHOUT drawing.  Two draws from the stream otherwise."""
+    background = img == 0
+    f = img.astype("float32")
+    lo, hi = 75, 180
+    avg = f[~background].mean()
+    if avg <= lo or avg >= hi:
+        return f.astype("uint8")
+    p = (avg - lo) / (hi - lo)
+    if rng.random() < p:
+        f -= rng.random() * (avg - lo)
+    else:
+        f += rng.random() * (hi - avg)
+    out = np.clip(f, 0, 255).astype("uint8")
+    out[background] = 0
+    return out
 
 
 def augment_geometric(img_data, img, C, rng=np.random):
@@ -64,6 +86,9 @@ def augment_geometric(img_data, img, C, rng=np.random):
                 b["x1"], b["x2"], b["y1"], b["y2"] = cols - x2, cols - x1, rows - y2, rows - y1
             else:
                 b["x1"], b["x2"], b["y1"], b["y2"] = rows - y2, rows - y1, x1, x2
+    # (use_rotations / use_shear, augmentation.py:506-512, would draw here: refused by TileFeed, see the module docstring)
+    if getattr(C, "use_brightness", False) and rng.random() < 0.5:          # augmentation.py:514-516
+        img = brightness(np.ascontiguousarray(img), rng)
     img_data["width"], img_data["height"] = img.shape[1], img.shape[0]
     return img_data, np.ascontiguousarray(img)
 

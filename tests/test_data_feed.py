@@ -122,6 +122,7 @@ def test_geometric_augmentations_vs_loop_restatement():
     boxes = [{"class": "boat", "x1": 5, "y1": 7, "x2": 20, "y2": 30}, {"class": "human", "x1": 0, "y1": 0, "x2": 53, "y2": 37}]
     C = Config()
     C.use_horizontal_flips = C.use_vertical_flips = C.use_90_rotations = True
+    C.use_brightness = False
     for hf in (False, True):
         for vf in (False, True):
             for angle in (None, 90, 180, 270):
@@ -172,3 +173,22 @@ def test_run_training_announces_the_right_batches():
     ts = Recorder()
     F.run_training(ts, ({"id": i} for i in range(9)), 3, lookahead=0)
     assert ts.calls == [(0, []), (1, []), (2, [])]
+
+
+def test_brightness_matches_reference_outputs():
+    """augmentation.brightness (augmentation.py:303-333) is pure NumPy in the reference: tests/golden/brightness.npz holds its
+    outputs and the position of the global random stream afterwards (tools/gen_golden_feed.py) for six images x three seeds,
+    incl. the no-draw early returns and channel-wise background pixels.  Byte-exact, same stream consumption."""
+    import os
+    from faster_rcnn import data_feed as F
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "brightness.npz"), allow_pickle=False)
+    changed = 0
+    for ci in range(int(g["n_cases"])):
+        img = g["c%d_img" % ci]
+        for si, seed in enumerate(g["seeds"]):
+            np.random.seed(int(seed))
+            out = F.brightness(img.copy())
+            assert out.dtype == np.uint8 and np.array_equal(out, g["c%d_s%d_out" % (ci, si)]), (ci, si)
+            assert int(np.random.randint(0, 2 ** 31 - 1)) == int(g["c%d_s%d_after" % (ci, si)]), (ci, si)
+            changed += int(not np.array_equal(out, img))
+    assert changed >= 9                          # the in-range images really were shifted

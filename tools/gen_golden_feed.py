@@ -50,6 +50,25 @@ def main():
         clipped, mask = raug.clip_box(b.copy(), box, alpha)
         out["clip_box"].append({"boxes": b.tolist(), "img_box": box, "alpha": alpha, "clipped": clipped.tolist(), "mask": [bool(m) for m in mask]})
 
+    # ---- augmentation.brightness (pure NumPy in the reference): images + the global-stream seed -> outputs + stream position
+    bright = {}
+    rsb = np.random.RandomState(31)
+    specs = [("mid", 120, 40), ("dark_skip", 40, 10), ("bright_skip", 230, 10), ("low_mid", 85, 30), ("high_mid", 170, 25), ("with_background", 130, 50)]
+    for ci, (name, mean, spread) in enumerate(specs):
+        img = np.clip(rsb.normal(mean, spread, (37, 53, 3)), 1, 255).astype(np.uint8)
+        if name == "with_background":
+            img[:10, :20] = 0
+            img[20:, 30:, 1] = 0
+        for si, seed in enumerate((5, 6, 7)):
+            np.random.seed(seed)
+            res, _ = raug.brightness(img.copy(), [])
+            bright["c%d_s%d_out" % (ci, si)] = res
+            bright["c%d_s%d_after" % (ci, si)] = np.int64(np.random.randint(0, 2 ** 31 - 1))
+        bright["c%d_img" % ci] = img
+    bright["n_cases"] = np.int64(len(specs))
+    bright["seeds"] = np.array([5, 6, 7], dtype=np.int64)
+    np.savez_compressed(os.path.join(G.OUT, "brightness.npz"), **bright)
+
     # ---- SampleSelector ---------------------------------------------------------------------------------------------
     counts = {"boat": 3, "human": 0, "other": 5, "animal": 1, "circle": 0, "wheel": 2}
     sel = rutils.SampleSelector(counts)
