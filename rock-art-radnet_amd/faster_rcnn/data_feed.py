@@ -9,13 +9,11 @@ Same control flow and the same draws from the random stream as the reference, in
   tile (drop those left with less than C.tile_bbox_clip_threshold of their area) -> tile coordinates (int / ceil) ->
   skip empty tiles and tiles without the class whose turn it is -> resize to get_new_img_size (bicubic, on the device);
   then the full image when C.include_full_img.
-Augmentation (augmentation.py:85-533): the three exact geometric ones are built -- horizontal / vertical
-flip, rotation by 90 / 180 / 270 degrees (augmentation.py:85-159; array reversals and transposes, so no interpolation is
-involved), with the reference's draws (np.random.random() < 0.5 per enabled switch, in its order; np.random.choice over
-the angle), and the brightness shift (augmentation.py:303-333: pure NumPy in the reference, pinned by the reference's own
-outputs -- tests/golden/brightness.npz).  Arbitrary rotation, shear and the noise / contrast family need OpenCV /
-scikit-image semantics that cannot be pinned here: in train mode those switches must be off (NotImplementedError otherwise).  Images are decoded by the caller (`load_image(img_data, img_type) -> uint8 BGR
-HWC`): OpenCV, which the reference decodes with, is not part of this build.
+Augmentation (augmentation.py:85-533) is `faster_rcnn/augmentation.py` of this package: every switch of
+the reference's Config (flips, 90-degree and +-3-degree rotation, shear, brightness, the noise / contrast family) with the
+reference's draws in its order; which parts are pinned by the reference's own outputs and which restate OpenCV /
+scikit-image semantics unpinned is listed in that module's header.  Images are decoded by the caller
+(`load_image(img_data, img_type) -> uint8 BGR HWC`): OpenCV, which the reference decodes with, is not part of this build.
 
 rng: None = NumPy's global stream, i.e. exactly the reference's interleaving with the step's own draws when samples are
 pulled one per step; pass a RandomState to pull samples AHEAD of the step (TrainStep's `upcoming` lookahead) without
@@ -27,70 +25,22 @@ import math
 
 import numpy as np
 
+from . import augmentation
 from .utils import get_new_img_size
 
-AUGMENT_SWITCHES = ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear",
-                    "use_brightness", "use_noise")          # augmentation.py:495-518
-EXACT_AUGMENTATIONS = AUGMENT_SWITCHES[:3] + ("use_brightness",)
+AUGMENT_SWITCHES = augmentation.AUGMENT_SWITCHES              # augmentation.py:495-518
+EXACT_AUGMENTATIONS = AUGMENT_SWITCHES[:3] + ("use_brightness",)   # no library semantics involved (see augmentation.py)
 
 
 def brightness(img, rng=np.random):
-    """augmentation.brightness (augmentation.py:303-333): pixels that are exactly 0 (in a channel) are background and stay 0;
-    the rest moves darker with probability p = (mean - 75) / 105 by U[0,1) * (mean - 75), else lighter by U[0,1) *
-    (180 - mean), in float32, clipped to [0, 255] and truncated to uint8.  Images whose foreground mean is outside (75, 180)
-    are returned unchanged WITHOUT drawing.  Two draws from the stream otherwise."""
-    background = img == 0
-    f = img.astype("float32")
-    lo, hi = 75, 180
-    avg = f[~background].mean()
-    if avg <= lo or avg >= hi:
-        return f.astype("uint8")
-    p = (avg - lo) / (hi - lo)
-    if rng.random() < p:
-        f -= rng.random() * (avg - lo)
-    else:
-        f += rng.random() * (hi - avg)
-    out = np.clip(f, 0, 255).astype("uint8")
-    out[background] = 0
-    return out
+    """augmentation.brightness on an image alone (kept for callers that have no boxes)."""
+    return augmentation.brightness(img, [], rng=rng)[0]
 
 
-def augment_geometric(img_data, img, C, rng=np.random):
-    """augmentation.augment (augmentation.py:481-533) restricted to its exact geometric branches; img_data['bboxes'] is
-    edited in place like the reference edits its deep copy.  Returns (img_data, img) with width / height updated."""
-    boxes = img_data["bboxes"]
-    if C.use_horizontal_flips and rng.random() < 0.5:           # augmentation.py:85-99: x -> cols - x, ends swapped
-        cols = img.shape[1]
-        img = img[:, ::-1]
-        for b in boxes:
-            b["x1"], b["x2"] = cols - b["x2"], cols - b["x1"]
-    if C.use_vertical_flips and rng.random() < 0.5:             # augmentation.py:101-115
-        rows = img.shape[0]
-        img = img[::-1]
-        for b in boxes:
-            b["y1"], b["y2"] = rows - b["y2"], rows - b["y1"]
-    if C.use_90_rotations and rng.random() < 0.5:               # augmentation.py:117-159
-        rows, cols = img.shape[:2]
-        angle = rng.choice([90, 180, 270], 1)[0]
-        if angle == 270:
-            img = np.transpose(img, (1, 0, 2))[::-1]
-        elif angle == 180:
-            img = img[::-1, ::-1]
-        else:
-            img = np.transpose(img, (1, 0, 2))[:, ::-1]
-        for b in boxes:
-            x1, x2, y1, y2 = b["x1"], b["x2"], b["y1"], b["y2"]
-            if angle == 270:
-                b["x1"], b["x2"], b["y1"], b["y2"] = y1, y2, cols - x2, cols - x1
-            elif angle == 180:
-                b["x1"], b["x2"], b["y1"], b["y2"] = cols - x2, cols - x1, rows - y2, rows - y1
-            else:
-                b["x1"], b["x2"], b["y1"], b["y2"] = rows - y2, rows - y1, x1, x2
-    # (use_rotations / use_shear, augmentation.py:506-512, would draw here: refused by TileFeed, see the module docstring)
-    if getattr(C, "use_brightness", False) and rng.random() < 0.5:          # augmentation.py:514-516
-        img = brightness(np.ascontiguousarray(img), rng)
-    img_data["width"], img_data["height"] = img.shape[1], img.shape[0]
-    return img_data, np.ascontiguousarray(img)
+def augment_geometric(img_data, img, C, rng=np.random, noise_rng=None):
+    """augmentation.augment (augmentation.py:481-533) for the feed: every switch of the reference, its draw order; returns
+    (img_data copy with the augmented boxes / width / height, image)."""
+    return augmentation.augment(img_data, img, C, augment=True, rng=rng, noise_rng=noise_rng)
 
 
 def get_data(annot_path, data_path, img_types, load_image):
@@ -180,10 +130,6 @@ class TileFeed:
         self.rng = np.random if rng is None else rng
         self.selector = SampleSelector(class_count)
         self.resize = resize                      # (img, new_w, new_h) -> img; default: the device bicubic kernel
-        if train_mode:
-            on = [k for k in AUGMENT_SWITCHES if getattr(C, k, False) and k not in EXACT_AUGMENTATIONS]
-            if on:
-                raise NotImplementedError("only the exact geometric augmentations are built (SURVEY.md 8f N4): switch off " + ", ".join(on))
 
     def _image(self, img_data, random_type):
         types = self.C.img_types

@@ -87,10 +87,9 @@ def test_tile_feed_matches_reference_generator(case):
     assert np.random.randint(0, 2 ** 31 - 1) == case["rng_after"]
 
 
-def test_augmentation_switches_are_refused_and_private_rng():
+def test_default_config_feeds_and_private_rng():
     C = Config()
-    with pytest.raises(NotImplementedError):
-        F.TileFeed([], C, {"boat": 1}, None, train_mode=True)          # the default Config has the augmentations on
+    F.TileFeed([], C, {"boat": 1}, None, train_mode=True)              # the default Config has every augmentation on: accepted
     for k in AUG:
         setattr(C, k, False)
     C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, False
@@ -122,12 +121,12 @@ def test_geometric_augmentations_vs_loop_restatement():
     boxes = [{"class": "boat", "x1": 5, "y1": 7, "x2": 20, "y2": 30}, {"class": "human", "x1": 0, "y1": 0, "x2": 53, "y2": 37}]
     C = Config()
     C.use_horizontal_flips = C.use_vertical_flips = C.use_90_rotations = True
-    C.use_brightness = False
+    C.use_brightness = C.use_rotations = C.use_shear = C.use_noise = False
     for hf in (False, True):
         for vf in (False, True):
             for angle in (None, 90, 180, 270):
                 coins = [0.1 if hf else 0.9, 0.1 if vf else 0.9, 0.1 if angle else 0.9]
-                data = {"bboxes": [dict(b) for b in boxes], "width": 53, "height": 37}
+                data = {"filepath": "t.png", "bboxes": [dict(b) for b in boxes], "width": 53, "height": 37}
                 d, out = F.augment_geometric(data, img, C, FixedRng(coins, angle))
                 rb, rimg = augment_geometric_loops(boxes, img, (hf, vf), angle)
                 assert np.array_equal(out, rimg) and d["bboxes"] == rb
@@ -137,7 +136,7 @@ def test_geometric_augmentations_vs_loop_restatement():
     # a switched-off augmentation draws nothing
     C.use_vertical_flips = False
     rng = FixedRng([0.9, 0.9], 90)
-    F.augment_geometric({"bboxes": [], "width": 53, "height": 37}, img, C, rng)
+    F.augment_geometric({"filepath": "t.png", "bboxes": [], "width": 53, "height": 37}, img, C, rng)
     assert rng.coins == []
 
 
