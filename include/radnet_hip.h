@@ -47,7 +47,10 @@ int radnet_set_workspace(radnet_ctx* ctx, void* ws, uint64_t bytes);
 /* Autotuning of the conv GEMM launch shape.  While enabled, the FIRST conv_fwd / conv_dgrad / conv_wgrad call of
  * each problem shape times every (output tile, split-K) candidate on the ctx stream (synchronising it) and caches
  * the fastest; later calls of that shape reuse the choice.  Shapes are static per image size, so a warm-up step
- * tunes the whole layer program.  radnet_tuned_shapes() returns the number of cached shapes. */
+ * tunes the whole layer program.  radnet_tuned_shapes() returns the number of cached shapes.
+ * enable = 2: as 1, but a new shape first adopts the cached choice of the shape that differs from it in M only, by at most
+ * M/4 (nearest M), and is measured only when there is none -- for training on tiles whose size changes from sample to
+ * sample (rotation / shear augmentation, augmentation.py:158-271), where every new size would otherwise re-tune every layer. */
 int radnet_set_autotune(radnet_ctx* ctx, int enable);
 int radnet_tuned_shapes(radnet_ctx* ctx);
 /* Persist / restore the measured choices (text, one shape per line).  A context that loaded a table runs no trial

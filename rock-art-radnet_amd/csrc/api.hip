@@ -53,7 +53,7 @@ extern "C" int radnet_set_stream(radnet_ctx* ctx, void* hip_stream) {
 
 extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
   if (!ctx) return RADNET_ERR_ARG;
-  ctx->autotune = enable ? 1 : 0;
+  ctx->autotune = enable == 2 ? 2 : (enable ? 1 : 0);
   return RADNET_OK;
 }
 

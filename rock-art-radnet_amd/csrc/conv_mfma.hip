@@ -1153,6 +1153,9 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     if (tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
   } else if (it != ctx->tuned->end()) {
     tc = TileChoice{it->second.a, it->second.b, it->second.splits, it->second.waves == 8 ? 8 : 4};
+  } else if (const radnet_tuned* nb = ctx->autotune == 2 ? radnet_tuned_neighbour(*ctx->tuned, key) : nullptr) {
+    tc = TileChoice{nb->a, nb->b, nb->splits, nb->waves == 8 ? 8 : 4};
+    (*ctx->tuned)[key] = *nb;
   } else if (ctx->autotune) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int chunks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};      // K slices per tile
@@ -1318,6 +1321,10 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced k tile %d does not divide c=%d", bmk, d->c);
   } else if (it != ctx->tuned->end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
+  } else if (const radnet_tuned* nb = (ctx->autotune == 2 && d->dw_accumulate != 1) ? radnet_tuned_neighbour(*ctx->tuned, key) : nullptr;
+             nb && (nb->splits <= 1 || (nmt / nb->splits >= 2 && radnet_cdiv(nmt, radnet_cdiv(nmt, nb->splits)) == nb->splits))) {
+    bmk = nb->a; bn = nb->b; splits = nb->splits;
+    (*ctx->tuned)[key] = *nb;
   } else if (ctx->autotune && d->dw_accumulate != 1) {
     struct WCand { float ms; int bmk, bn, s; };
     std::vector<WCand> seen;

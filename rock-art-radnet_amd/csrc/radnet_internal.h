@@ -35,6 +35,21 @@ struct radnet_tuned {
   int waves = 4;
 };
 
+// Autotune mode 2 (radnet_set_autotune): a problem shape not measured yet adopts the choice of the measured shape that
+// differs from it in M only, by at most M/4 (training on tiles whose size changes from sample to sample: every layer's M
+// moves with the image, N / K / taps do not).  Nearest M wins; nullptr when there is none.
+inline const radnet_tuned* radnet_tuned_neighbour(const std::map<radnet_shape_key, radnet_tuned>& table, const radnet_shape_key& key) {
+  const radnet_tuned* best = nullptr;
+  int best_d = key.m / 4 + 1;
+  for (const auto& kv : table) {
+    const radnet_shape_key& o = kv.first;
+    if (o.kind != key.kind || o.n != key.n || o.k != key.k || o.c != key.c || o.npos != key.npos || o.stride != key.stride) continue;
+    const int d = o.m > key.m ? o.m - key.m : key.m - o.m;
+    if (d < best_d) { best_d = d; best = &kv.second; }
+  }
+  return best;
+}
+
 // Device-resident work-unit / fix-up tables of a K-split GEMM launch (conv_mfma.hip: get_unit_table).
 struct radnet_unit_table {
   int* d_units = nullptr;

@@ -159,7 +159,9 @@ class FasterRCNNEngine:
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
-        self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, 1 if autotune else 0), "set_autotune")
+        # 0 off / 1 measure every new GEMM shape / 2 adopt the nearest measured M first (variable tile sizes, lib header)
+        self.autotune_mode = int(os.environ.get("RADNET_AUTOTUNE", int(autotune))) if autotune else 0
+        self.ctx.check(self.lib.radnet_set_autotune(self.ctx.h, self.autotune_mode), "set_autotune")
         # Lanes: further contexts on their own streams (TrainStep's pipelined step, see lane()).  (Forking only the wgrad
         # GEMMs of a backward program to a second stream was measured too: 3.48 ms/step against 3.41 on one stream.)
         # A separate upload stream is OFF by default: with the lanes in place the upload already runs on a prefetch lane,
@@ -169,12 +171,12 @@ class FasterRCNNEngine:
         self.copy_stream = torch.cuda.Stream(device=self.dev) if self.use_copy_stream else None
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self.ctx2 = L.Context(device_index, stream_handle=self.side_stream.cuda_stream)
-        self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, 1 if autotune else 0), "set_autotune")
+        self.ctx2.check(self.lib.radnet_set_autotune(self.ctx2.h, self.autotune_mode), "set_autotune")
         self.ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
         self.ctx2.check(self.lib.radnet_set_workspace(self.ctx2.h, self.ws2.data_ptr(), self.ws2.numel()), "set_workspace")
         self.head_stream = torch.cuda.Stream(device=self.dev)
         self.ctx3 = L.Context(device_index, stream_handle=self.head_stream.cuda_stream)
-        self.ctx3.check(self.lib.radnet_set_autotune(self.ctx3.h, 1 if autotune else 0), "set_autotune")
+        self.ctx3.check(self.lib.radnet_set_autotune(self.ctx3.h, self.autotune_mode), "set_autotune")
         self.ws3 = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
         self.ctx3.check(self.lib.radnet_set_workspace(self.ctx3.h, self.ws3.data_ptr(), self.ws3.numel()), "set_workspace")
         self._lanes = {"side": (self.ctx2, self.side_stream), "head": (self.ctx3, self.head_stream)}
@@ -185,7 +187,7 @@ class FasterRCNNEngine:
         for k in range(1, self.n_side_lanes):
             st = torch.cuda.Stream(device=self.dev)
             cx = L.Context(device_index, stream_handle=st.cuda_stream)
-            cx.check(self.lib.radnet_set_autotune(cx.h, 1 if autotune else 0), "set_autotune")
+            cx.check(self.lib.radnet_set_autotune(cx.h, self.autotune_mode), "set_autotune")
             ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)
             cx.check(self.lib.radnet_set_workspace(cx.h, ws.data_ptr(), ws.numel()), "set_workspace")
             self._extra_lanes.append((st, cx, ws))

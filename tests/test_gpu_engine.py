@@ -400,3 +400,51 @@ def test_run_training_from_tile_feed():
     for name in ("rpn_conv1", "res5a_branch2a", "dense_class_7"):
         d = np.abs(w0[name]["kernel"] - w1[name]["kernel"])
         assert d.max() < 5e-6 and np.mean(d < 3e-7) > 0.999, (name, float(d.max()), float(np.mean(d < 3e-7)))
+
+
+def test_default_config_augmentations_train_on_changing_tile_sizes():
+    """The reference's DEFAULT Config has every augmentation on (config.py:19-26); rotation and shear change the tile size
+    from sample to sample.  TileFeed -> TrainStep with the default switches: every step finishes with finite losses, sizes do
+    change, and with autotune mode 2 (adopt the nearest measured M) later new sizes plan much faster than the first ones."""
+    import time
+    from faster_rcnn import data_feed as F
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    assert all(getattr(C, k) for k in F.AUGMENT_SWITCHES)
+    C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, False
+    rs = np.random.RandomState(8)
+    classes = [k for k in C.class_mapping if k != "bg"]
+    data, imgs = [], {}
+    for i, (w, h) in enumerate([(640, 480), (500, 700)]):
+        boxes = []
+        for j in range(8):
+            bw, bh = int(rs.randint(50, 140)), int(rs.randint(50, 140))
+            x1, y1 = int(rs.randint(0, w - bw)), int(rs.randint(0, h - bh))
+            boxes.append({"class": classes[j % len(classes)], "x1": x1, "x2": x1 + bw, "y1": y1, "y2": y1 + bh})
+        data.append({"filepath": "img%d" % i, "width": w, "height": h, "bboxes": boxes})
+        imgs["img%d" % i] = rs.randint(1, 256, (h, w, 3)).astype(np.uint8)
+    class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in classes}
+    eng = FasterRCNNEngine(C, autotune=2)
+    eng.set_weights(dense.init_params(seed=3))
+    np.random.seed(11)
+    ts = TrainStep(eng)
+    feed = iter(F.TileFeed(data, C, class_count, lambda d, t: imgs[d["filepath"]], rng=np.random.RandomState(2)))
+    sizes, took = [], []
+    for k in range(16):
+        s = next(feed)
+        sizes.append(s["img"].shape[:2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ts.step([s])
+        ts.flush()
+        torch.cuda.synchronize()
+        took.append(time.perf_counter() - t0)
+        lo = ts.losses()
+        assert lo["dropped"] == 1 or all(np.isfinite(lo[k]) for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr")), lo
+    print("sizes", sizes, "seconds per step", ["%.2f" % t for t in took])
+    assert len(set(sizes)) >= 2, sizes                 # (the resize to img_size on the short side absorbs pure rotations)
+    new = [i for i in range(16) if sizes[i] not in sizes[:i]]
+    assert min(took[i] for i in new[1:]) < 0.5 * took[0], (new, took)

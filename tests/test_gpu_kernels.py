@@ -120,6 +120,38 @@ def test_conv_fwd_sigmoid_head_columns(ctx):
 DGRAD_CASES = [(2, 7, 7, 512, 512, 3, 1), (2, 7, 7, 512, 2048, 1, 0), (1, 13, 17, 2048, 512, 1, 0), (1, 12, 9, 512, 64, 1, 0), (1, 38, 63, 128, 128, 3, 1)]
 
 
+def test_autotune_adopts_the_nearest_measured_shape(ctx):
+    """radnet_set_autotune(2): the first 1x1 conv at M = 40*50 is measured; the same layer at M = 40*53 (within M/4) adopts
+    its launch shape without measuring (one more cached shape, far fewer launches), at M = 40*80 it is measured again.  All
+    three results against the oracle."""
+    import time
+    from radnet_hip import lib as L
+    from oracle import dense
+    rs = np.random.RandomState(12)
+    cin, cout = 192, 160                                   # a shape no other test of this module uses
+    wt = (rs.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    wd = dev(wt.reshape(-1, cout))
+    n0 = ctx.lib.radnet_tuned_shapes(ctx.h)
+    ctx.check(ctx.lib.radnet_set_autotune(ctx.h, 2), "autotune 2")
+    took = []
+    try:
+        for w_ in (50, 53, 80):
+            x = rs.standard_normal((1, 40, w_, cin)).astype(np.float32)
+            xd = dev(x)
+            y = torch.full((1, 40, w_, cout), float("nan"), dtype=torch.float32, device="cuda")
+            d = conv_desc(L, xd, wd, y, 1, 40, w_, cin, 40, w_, 1, 1, 0, cout, cout)
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd")
+            ctx.sync()
+            took.append(time.perf_counter() - t0)
+            close(y.cpu().numpy(), dense.conv2d(x.astype(np.float64), wt.astype(np.float64), None, 1, (0, 0, 0, 0)))
+    finally:
+        ctx.check(ctx.lib.radnet_set_autotune(ctx.h, 0), "autotune off")
+    assert ctx.lib.radnet_tuned_shapes(ctx.h) == n0 + 3
+    assert took[1] * 5 < took[0] and took[1] * 5 < took[2], took      # adopted, not measured
+
+
 @pytest.mark.parametrize("case", DGRAD_CASES)
 def test_conv_dgrad_wgrad(ctx, case):
     """dgrad (with BN scale on dy, residual-path add and the producer's ReLU mask fused) and wgrad + bias colsum."""
