@@ -99,9 +99,9 @@ def _time_us(fn, n=30, warm=5):
 
 def layers_3x3_table(eng, bp, rp):
     """north_star target "MFMA utilisation on ResNet50 stage-3/4 3x3 convs" (+ rpn_conv1), per layer class, each form alone on
-    the chip, back-to-back launches between two HIP events on the launch stream: the Winograd F(2x2,3x3) form the step runs
-    (input transform + 16 batched GEMMs + output transform with BN/ReLU) and the direct implicit GEMM.  `executed` = flops the
-    MFMAs really perform (Winograd: 2*16*tiles*C*N), `algorithmic` = 2*M*N*9C; fractions are of 157.3 TFLOP/s."""
+    the chip, back-to-back launches between two HIP events on the launch stream: the Winograd form the step runs (F(4x4,3x3) or
+    F(2x2,3x3): input transform + 36 / 16 batched GEMMs + output transform with BN/ReLU) and the direct implicit GEMM.
+    `executed` = flops the MFMAs really perform (Winograd: 2*positions*tiles*C*N), `algorithmic` = 2*M*N*9C; fractions are of 157.3 TFLOP/s."""
     import ctypes as C
     lib = eng.lib
     rows = []
@@ -119,24 +119,26 @@ def layers_3x3_table(eng, bp, rp):
         if name not in found:
             continue
         c = eng.convs[name]
-        x, nb, hh, ww, cin, n, V, U, M, T, scale, shift, act, y, ldy = found[name]
+        x, nb, hh, ww, cin, n, V, U, M, T, scale, shift, act, y, ldy, form = found[name]
         h = eng.ctx.h
-        t_in = _time_us(lambda: lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V))
+        P = (form + 2) ** 2
+        w_in, w_out = (lib.radnet_winograd4_input, lib.radnet_winograd4_output) if form == 4 else (lib.radnet_winograd_input, lib.radnet_winograd_output)
+        t_in = _time_us(lambda: w_in(h, x, nb, hh, ww, cin, V))
         gemm = lib.radnet_gemm_batched
-        t_g = _time_us(lambda: gemm(h, V, U, M, 16, T, n, cin))
-        t_out = _time_us(lambda: lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy))
+        t_g = _time_us(lambda: gemm(h, V, U, M, P, T, n, cin))
+        t_out = _time_us(lambda: w_out(h, M, nb, hh, ww, n, scale, shift, act, y, ldy))
 
         def layer():
-            lib.radnet_winograd_input(h, x, nb, hh, ww, cin, V)
-            gemm(h, V, U, M, 16, T, n, cin)
-            lib.radnet_winograd_output(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
+            w_in(h, x, nb, hh, ww, cin, V)
+            gemm(h, V, U, M, P, T, n, cin)
+            w_out(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
         t_layer = _time_us(layer)
         d, _, _ = eng._desc(c, _Ptr(x), nb, hh, ww, _Ptr(y), relu=bool(act))
         t_dir = _time_us(lambda: lib.radnet_conv_fwd(h, C.byref(d)))
         algo = 2.0 * nb * hh * ww * n * 9 * cin
-        execd = 2.0 * 16 * T * cin * n
-        rows.append({"layer": label, "M": nb * hh * ww, "N": n, "K": 9 * cin, "tiles": T,
-                     "winograd_us": {"input_transform": t_in, "gemm_16x": t_g, "output_transform": t_out, "layer_back_to_back": t_layer},
+        execd = 2.0 * P * T * cin * n
+        rows.append({"layer": label, "M": nb * hh * ww, "N": n, "K": 9 * cin, "tiles": T, "winograd_form": "F(%dx%d,3x3)" % (form, form),
+                     "winograd_us": {"input_transform": t_in, "gemm_batched": t_g, "gemms": P, "output_transform": t_out, "layer_back_to_back": t_layer},
                      "direct_us": t_dir, "algorithmic_gflop": algo / 1e9, "winograd_executed_gflop": execd / 1e9,
                      "winograd_gemm_executed_tflops": execd / t_g / 1e6, "winograd_gemm_executed_frac": execd / t_g / 1e6 / PEAK_FP32_MFMA_TFLOPS,
                      "winograd_layer_algorithmic_tflops": algo / t_layer / 1e6, "winograd_layer_algorithmic_frac": algo / t_layer / 1e6 / PEAK_FP32_MFMA_TFLOPS,
@@ -369,7 +371,7 @@ def main():
                 "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
                 "schedule": "one lane, launches isolated (each GEMM launch alone on the chip between two HIP events); `value` is measured on the "
                             "pipelined schedule, where lanes overlap -- gemm_ms_per_image here may exceed ms_per_step",
-                "winograd_credit": "Winograd layers are timed per layer (3 kernels) and credited the algorithmic 2*M*N*9C flops, not the 2.25x fewer they execute",
+                "winograd_credit": "Winograd layers are timed per layer (3 kernels) and credited the algorithmic 2*M*N*9C flops, not the 4x (F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer they execute",
                 "executed_tflops": exec_fl / max(tot_ms, 1e-9) / 1e9, "executed_frac": exec_fl / max(tot_ms, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,
                 "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}

@@ -132,6 +132,17 @@ int radnet_winograd_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh,
 int radnet_wgrad_batched(radnet_ctx* ctx, const float* a, const float* dy, float* dw, int32_t batch, int32_t m, int32_t k, int32_t n,
                          int32_t accumulate);
 int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate);
+/* The same five transforms for Winograd F(4x4,3x3): 36 positions instead of 16 (u [36][c][n], v [36][tiles][c], m / dz
+ * [36][tiles][n], batch 36 in radnet_gemm_batched / radnet_wgrad_batched) over tiles = nb*ceil(h/4)*ceil(w/4) -- 4x fewer
+ * matrix-core flops than the direct 3x3 form, 1.78x fewer than F(2x2), and 0.56x the transform traffic of F(2x2); the fp32
+ * result is off by about 2e-5 of the largest activation from the fp64 sum (F(2x2): 1e-6), inside the stated 2e-4. */
+int radnet_winograd4_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u);
+int radnet_winograd4_input(radnet_ctx* ctx, const float* x, int32_t nb, int32_t h, int32_t w, int32_t c, float* v);
+int radnet_winograd4_output(radnet_ctx* ctx, const float* m, int32_t nb, int32_t oh, int32_t ow, int32_t n, const float* scale,
+                            const float* shift, int32_t act, float* y, int32_t ldy);
+int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh, int32_t ow, int32_t n, int32_t ld_dy,
+                        const float* gscale, float* dz);
+int radnet_winograd4_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate);
 int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 
@@ -282,9 +293,10 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  *   CONV_FWD / CONV_DGRAD / CONV_WGRAD   conv
  *   MAXPOOL      p: x, y                     i: nb, h, w, c, k, s
  *   COLSUM       p: g, gscale|0, out         i: m, n, ld, accumulate
- *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy   (radnet_winograd_input + 16 GEMMs
- *   WINO_REUSE   same, v already holds this input's transform                                   + radnet_winograd_output)
- *   WINO_WGRAD   p: dy, v, dz, du, dw        i: nb, h, w, c, n, ld_dy, tiles, ldw, accumulate mode (as radnet_conv_desc)
+ *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy, form   (radnet_winograd_input + 16
+ *   WINO_REUSE   same, v already holds this input's transform                             GEMMs + radnet_winograd_output;
+ *                                                                         form 4: the radnet_winograd4_* transforms, 36 GEMMs)
+ *   WINO_WGRAD   p: dy, v, dz, du, dw        i: nb, h, w, c, n, ld_dy, tiles, ldw, accumulate mode (as radnet_conv_desc), form
  *   SCATTER      p: src, mask|0, dst         i: nb, oh, ow, c, stride, h, w
  *   FILL0        p: dst                      i: bytes (low 32 bits), bytes (high 32 bits)
  *   RELU_MASK    p: g, act                   i: n (low), n (high)
@@ -368,7 +380,7 @@ typedef struct radnet_train_desc {
   const radnet_op* rpn_refwd_ops; int32_t n_rpn_refwd;
   float* pred; float* dz; int32_t ld_pred, fh, fw, a, bce_mode; double* loss_scratch8; float* rpn_losses;
   radnet_adam_desc rpn_opt, head_opt; int32_t world;
-  const float* wino_w; int32_t wino_c, wino_n, wino_ldw; float* wino_u;
+  const float* wino_w; int32_t wino_c, wino_n, wino_ldw, wino_form; float* wino_u;   /* rpn_conv1 filter re-transform after Adam #1; form 4 = F(4x4) */
   const double* anchor_wh_host; double overlap_thresh; int32_t max_boxes;
   int64_t* R; float* Rp; int32_t* Rn; void* prop_ws;
   int32_t rw, rh; double min_overlap, max_overlap; const double* regr_std_host4; int32_t bg_class;

@@ -27,15 +27,17 @@ int run_wino(radnet_ctx* ctx, const radnet_op& o, bool reuse) {
   const float* shift = (const float*)o.p[5];
   float* y = (float*)o.p[6];
   const int nb = o.i[0], h = o.i[1], w = o.i[2], c = o.i[3], n = o.i[4], T = o.i[5], act = o.i[6], ldy = o.i[7];
+  const bool f4 = o.i[8] == 4;                 // Winograd output tile: 4 = F(4x4,3x3) (36 positions), else F(2x2,3x3) (16)
   // roofline leg: the LAYER is timed (three kernels) and credited its algorithmic flops (class 3)
   const int timed = ctx->timing;
   if (timed) {
     radnet_timing_begin(ctx);
     ctx->timing = 0;
   }
-  int rc = reuse ? RADNET_OK : radnet_winograd_input(ctx, x, nb, h, w, c, V);
-  if (rc == RADNET_OK) rc = radnet_gemm_batched(ctx, V, U, M, 16, T, n, c);
-  if (rc == RADNET_OK) rc = radnet_winograd_output(ctx, M, nb, h, w, n, scale, shift, act, y, ldy);
+  int rc = reuse ? RADNET_OK : (f4 ? radnet_winograd4_input(ctx, x, nb, h, w, c, V) : radnet_winograd_input(ctx, x, nb, h, w, c, V));
+  if (rc == RADNET_OK) rc = radnet_gemm_batched(ctx, V, U, M, f4 ? 36 : 16, T, n, c);
+  if (rc == RADNET_OK)
+    rc = f4 ? radnet_winograd4_output(ctx, M, nb, h, w, n, scale, shift, act, y, ldy) : radnet_winograd_output(ctx, M, nb, h, w, n, scale, shift, act, y, ldy);
   if (timed) {
     ctx->timing = timed;
     radnet_timing_end(ctx, 3, 2.0 * nb * h * w * (double)n * 9.0 * c);
@@ -55,9 +57,11 @@ int run_wino_wgrad(radnet_ctx* ctx, const radnet_op& o) {
     radnet_timing_begin(ctx);
     ctx->timing = 0;
   }
-  int rc = radnet_winograd_dy(ctx, dy, nb, h, w, n, ld_dy, nullptr, dZ);
-  if (rc == RADNET_OK) rc = radnet_wgrad_batched(ctx, V, dZ, dU, 16, T, c, n, 0);
-  if (rc == RADNET_OK) rc = radnet_winograd_filter_grad(ctx, dU, c, n, ldw, dw, mode == 1 ? 1 : 0);
+  const bool f4 = o.i[9] == 4;
+  int rc = f4 ? radnet_winograd4_dy(ctx, dy, nb, h, w, n, ld_dy, nullptr, dZ) : radnet_winograd_dy(ctx, dy, nb, h, w, n, ld_dy, nullptr, dZ);
+  if (rc == RADNET_OK) rc = radnet_wgrad_batched(ctx, V, dZ, dU, f4 ? 36 : 16, T, c, n, 0);
+  if (rc == RADNET_OK)
+    rc = f4 ? radnet_winograd4_filter_grad(ctx, dU, c, n, ldw, dw, mode == 1 ? 1 : 0) : radnet_winograd_filter_grad(ctx, dU, c, n, ldw, dw, mode == 1 ? 1 : 0);
   if (timed) {
     ctx->timing = timed;
     radnet_timing_end(ctx, 3, 2.0 * nb * h * w * (double)n * 9.0 * c);
@@ -192,7 +196,9 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   if (rc == RADNET_OK)
     rc = radnet_adam_step(ctx, d->rpn_opt.p, d->rpn_opt.g, d->rpn_opt.m, d->rpn_opt.v, d->rpn_opt.n, d->rpn_opt.t, d->rpn_opt.lr, 0.9f, 0.999f,
                           1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
-  if (rc == RADNET_OK && d->wino_w) rc = radnet_winograd_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u);
+  if (rc == RADNET_OK && d->wino_w)
+    rc = d->wino_form == 4 ? radnet_winograd4_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u)
+                           : radnet_winograd_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u);
   // ---- phase D: re-predict with the updated RPN (train.py:291), proposals, RoI labelling
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, d->rpn_refwd_ops, d->n_rpn_refwd);
   if (rc == RADNET_OK)

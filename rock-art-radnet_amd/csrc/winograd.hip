@@ -221,6 +221,233 @@ __global__ void __launch_bounds__(256) wino_filter_grad_kernel(const float* __re
   }
 }
 
+// ---- F(4x4, 3x3): 6x6 input patches, 36 products per 4x4 output tile and channel pair instead of 144 (4x fewer matrix-core
+// flops than the direct form, 1.78x fewer than F(2x2)); interpolation points 0, +-1, +-2, inf (Lavin & Gray):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// The transforms multiply by up to 8 and by 1/24: against the fp64 direct sum the fp32 result is off by about 2e-5 of the
+// largest activation at C = 1024 (F(2x2): 1e-6, direct fp32: 5e-7) -- inside the 2e-4 the kernel tests state.
+// Layouts as above with 36 positions p = 6*xi + nu and tiles of 4x4 outputs (input rows 4ti-1 .. 4ti+4).
+__device__ __forceinline__ float4 f4s(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4fma(float4 a, float s, float4 b) { return make_float4(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z), fmaf(a.w, s, b.w)); }
+
+__device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&o)[6]) {          // o = B^T d
+  o[0] = f4fma(d[0], 4.f, f4fma(d[2], -5.f, d[4]));
+  const float4 p = f4fma(d[2], -4.f, d[4]), q = f4fma(d[1], -4.f, d[3]);
+  o[1] = f4add(p, q);
+  o[2] = f4sub(p, q);
+  const float4 r = f4sub(d[4], d[2]), t = f4s(f4sub(d[3], d[1]), 2.f);
+  o[3] = f4add(r, t);
+  o[4] = f4sub(r, t);
+  o[5] = f4fma(d[1], 4.f, f4fma(d[3], -5.f, d[5]));
+}
+__device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&o)[4]) {          // o = A^T m
+  const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]), s34 = f4add(m[3], m[4]), d34 = f4sub(m[3], m[4]);
+  o[0] = f4add(f4add(m[0], s12), s34);
+  o[1] = f4fma(d34, 2.f, d12);
+  o[2] = f4fma(s34, 4.f, s12);
+  o[3] = f4add(f4fma(d34, 8.f, d12), m[5]);
+}
+__device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&z)[6]) {           // z = A y (adjoint of at6)
+  const float4 e = f4add(y[0], y[2]), o = f4add(y[1], y[3]);
+  const float4 e4 = f4fma(y[2], 4.f, y[0]), o2 = f4fma(y[3], 8.f, f4s(y[1], 2.f));
+  z[0] = y[0];
+  z[1] = f4add(e, o);
+  z[2] = f4sub(e, o);
+  z[3] = f4add(e4, o2);
+  z[4] = f4sub(e4, o2);
+  z[5] = y[3];
+}
+__device__ __forceinline__ void g6(const float4 (&g)[3], float4 (&u)[6]) {           // u = G g
+  const float4 s = f4add(g[0], g[2]);
+  u[0] = f4s(g[0], 0.25f);
+  u[1] = f4s(f4add(s, g[1]), -1.f / 6.f);
+  u[2] = f4s(f4sub(s, g[1]), -1.f / 6.f);
+  const float4 a = f4fma(g[0], 1.f / 24.f, f4s(g[2], 1.f / 6.f)), b = f4s(g[1], 1.f / 12.f);
+  u[3] = f4add(a, b);
+  u[4] = f4sub(a, b);
+  u[5] = g[2];
+}
+__device__ __forceinline__ void gt6(const float4 (&u)[6], float4 (&w)[3]) {          // w = G^T u (adjoint of g6)
+  const float4 s12 = f4add(u[1], u[2]), s34 = f4add(u[3], u[4]);
+  w[0] = f4fma(u[0], 0.25f, f4fma(s12, -1.f / 6.f, f4s(s34, 1.f / 24.f)));
+  w[1] = f4fma(f4sub(u[2], u[1]), 1.f / 6.f, f4s(f4sub(u[3], u[4]), 1.f / 12.f));
+  w[2] = f4add(f4fma(s12, -1.f / 6.f, f4s(s34, 1.f / 6.f)), u[5]);
+}
+
+__global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restrict__ g, int C, int N, int ldw, float* __restrict__ U) {
+  const int n4 = N >> 2;
+  const long long total = (long long)C * n4, ps = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+    float4 t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float4 col[3], o[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) col[a] = *reinterpret_cast<const float4*>(g + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
+      g6(col, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a][b] = o[a];
+    }
+    float4* dst = reinterpret_cast<float4*>(U) + (long long)c * n4 + nq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float4 o[6];
+      g6(t[a], o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino4_input_kernel(const float* __restrict__ x, int nb, int H, int W, int C, int TH, int TW,
+                                                          float* __restrict__ V) {
+  const int c4 = C >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * c4, ps = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4);
+    const long long tile = i / c4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    float4 t[6][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int iw = 4 * tj - 1 + b;
+      float4 col[6], o[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int ih = 4 * ti - 1 + a;
+        col[a] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                     ? *reinterpret_cast<const float4*>(x + (((long long)img * H + ih) * W + iw) * C + cq * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      bt6(col, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a][b] = o[a];
+    }
+    float4* dst = reinterpret_cast<float4*>(V) + tile * c4 + cq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float4 o[6];
+      bt6(t[a], o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino4_output_kernel(const float* __restrict__ Mm, int nb, int OH, int OW, int N, int TH, int TW,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                           float* __restrict__ y, int ldy) {
+  const int n4 = N >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * n4, ps = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int nq = (int)(i % n4);
+    const long long tile = i / n4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    const float4* src = reinterpret_cast<const float4*>(Mm) + tile * n4 + nq;
+    float4 t[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float4 col[6], o[4];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) col[a] = src[(6 * a + b) * ps];
+      at6(col, o);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) t[a][b] = o[a];
+    }
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + nq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oh = 4 * ti + a;
+      float4 o[4];
+      at6(t[a], o);
+      if (oh >= OH) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ow = 4 * tj + b;
+        if (ow >= OW) continue;
+        float4 v = make_float4(fmaf(o[b].x, sc.x, sh.x), fmaf(o[b].y, sc.y, sh.y), fmaf(o[b].z, sc.z, sh.z), fmaf(o[b].w, sc.w, sh.w));
+        if (act == 1) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *reinterpret_cast<float4*>(y + (((long long)img * OH + oh) * OW + ow) * ldy + nq * 4) = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__ dy, int nb, int OH, int OW, int N, int ld_dy, int TH, int TW,
+                                                       const float* __restrict__ gscale, float* __restrict__ dZ) {
+  const int n4 = N >> 2;
+  const long long T = (long long)nb * TH * TW, total = T * n4, ps = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int nq = (int)(i % n4);
+    const long long tile = i / n4;
+    const int tj = (int)(tile % TW);
+    const int ti = (int)((tile / TW) % TH);
+    const int img = (int)(tile / ((long long)TW * TH));
+    const float4 gs = gscale ? *reinterpret_cast<const float4*>(gscale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 r[6][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ow = 4 * tj + b;
+      float4 col[4], o[6];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oh = 4 * ti + a;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oh < OH && ow < OW) v = *reinterpret_cast<const float4*>(dy + (((long long)img * OH + oh) * OW + ow) * ld_dy + nq * 4);
+        col[a] = make_float4(v.x * gs.x, v.y * gs.y, v.z * gs.z, v.w * gs.w);
+      }
+      a6(col, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][b] = o[a];
+    }
+    float4* dst = reinterpret_cast<float4*>(dZ) + tile * n4 + nq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float4 o[6];
+      a6(r[a], o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino4_filter_grad_kernel(const float* __restrict__ dU, int C, int N, int ldw, float* __restrict__ dw, int accumulate) {
+  const int n4 = N >> 2;
+  const long long total = (long long)C * n4, ps = total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+    const float4* src = reinterpret_cast<const float4*>(dU) + (long long)c * n4 + nq;
+    float4 t[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float4 col[6], o[3];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) col[a] = src[(6 * a + b) * ps];
+      gt6(col, o);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) t[a][b] = o[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float4 o[3];
+      gt6(t[a], o);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float4* q = reinterpret_cast<float4*>(dw + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
+        *q = accumulate ? f4add(*q, o[b]) : o[b];
+      }
+    }
+  }
+}
+
 inline int grid_of(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -275,3 +502,51 @@ extern "C" int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int
   return RADNET_OK;
 }
 
+
+// ---- F(4x4,3x3) entry points: same contracts with 36 positions and tiles = nb*ceil(h/4)*ceil(w/4) -----------------------
+extern "C" int radnet_winograd4_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u) {
+  if (!ctx || !w || !u) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  hipLaunchKernelGGL(wino4_filter_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, w, c, n, ldw, u);
+  RADNET_CHECK_LAUNCH(ctx, "winograd4_filter");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd4_input(radnet_ctx* ctx, const float* x, int32_t nb, int32_t h, int32_t w, int32_t c, float* v) {
+  if (!ctx || !x || !v) return RADNET_ERR_ARG;
+  if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_input: c=%d must be a multiple of 4", c);
+  const int th = (h + 3) / 4, tw = (w + 3) / 4;
+  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_of((long long)nb * th * tw * (c / 4))), dim3(256), 0, ctx->stream, x, nb, h, w, c, th, tw, v);
+  RADNET_CHECK_LAUNCH(ctx, "winograd4_input");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd4_output(radnet_ctx* ctx, const float* m, int32_t nb, int32_t oh, int32_t ow, int32_t n, const float* scale,
+                                       const float* shift, int32_t act, float* y, int32_t ldy) {
+  if (!ctx || !m || !y) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_output: n=%d, ldy=%d", n, ldy);
+  const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
+  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, m, nb, oh, ow, n, th, tw, scale,
+                     shift, act, y, ldy);
+  RADNET_CHECK_LAUNCH(ctx, "winograd4_output");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh, int32_t ow, int32_t n, int32_t ld_dy,
+                                   const float* gscale, float* dz) {
+  if (!ctx || !dy || !dz) return RADNET_ERR_ARG;
+  if ((n & 3) || (ld_dy & 3) || ld_dy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_dy: n=%d, ld_dy=%d", n, ld_dy);
+  const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
+  hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, dy, nb, oh, ow, n, ld_dy, th, tw,
+                     gscale, dz);
+  RADNET_CHECK_LAUNCH(ctx, "winograd4_dy");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_winograd4_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate) {
+  if (!ctx || !du || !dw) return RADNET_ERR_ARG;
+  if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter_grad: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  hipLaunchKernelGGL(wino4_filter_grad_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, du, c, n, ldw, dw, accumulate ? 1 : 0);
+  RADNET_CHECK_LAUNCH(ctx, "winograd4_filter_grad");
+  return RADNET_OK;
+}

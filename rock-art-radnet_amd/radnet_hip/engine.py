@@ -115,7 +115,8 @@ class ConvLayer:
         self.t0 = None          # BN shift without the conv bias (trainable convs refresh shift = scale*bias + t0)
         self.dweight = None
         self.dbias = None
-        self.wino_u = None      # Winograd-transformed filter [16][cin][cout] when the layer runs as F(2x2,3x3)
+        self.wino_u = None      # Winograd-transformed filter [(m+2)^2][cin][cout] when the layer runs as F(m x m, 3x3)
+        self.wino_m = 2         # output tile of the Winograd form: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
 
 
 class FasterRCNNEngine:
@@ -387,6 +388,16 @@ class FasterRCNNEngine:
     def _uses_winograd(self, c):
         return self.use_winograd and c.name in self.WINOGRAD_LAYERS and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
 
+    # F(4x4,3x3) (36 GEMMs on a quarter of the tiles) where it measured faster than F(2x2,3x3) at 1000x600
+    # (tools/winograd_timing.py; bench.py roofline.layers_3x3): RADNET_WINOGRAD_TILE=2 / 4 forces one form everywhere.
+    WINOGRAD_F4_LAYERS = WINOGRAD_LAYERS
+
+    def _wino_form(self, c):
+        forced = os.environ.get("RADNET_WINOGRAD_TILE")
+        if forced:
+            return 4 if forced == "4" else 2
+        return 4 if c.name in self.WINOGRAD_F4_LAYERS else 2
+
     def _refresh_winograd(self, names=None):
         """Filter transform U = G g G^T of the Winograd layers (all of them, or the named ones after a weight update)."""
         for name in (names if names is not None else self.WINOGRAD_LAYERS):
@@ -394,8 +405,9 @@ class FasterRCNNEngine:
             if c is None or not self._uses_winograd(c):
                 continue
             if c.wino_u is None:
-                c.wino_u = torch.empty(16, c.cin, c.cout, dtype=torch.float32, device=self.dev)
-            self.ctx.call("radnet_winograd_filter", c.weight, c.cin, c.cout, c.ldw, c.wino_u)
+                c.wino_m = self._wino_form(c)
+                c.wino_u = torch.empty((c.wino_m + 2) ** 2, c.cin, c.cout, dtype=torch.float32, device=self.dev)
+            self.ctx.call("radnet_winograd4_filter" if c.wino_m == 4 else "radnet_winograd_filter", c.weight, c.cin, c.cout, c.ldw, c.wino_u)
 
     def _fwd_op(self, c, x, nb, h, w, y, keep, relu=True):
         """Forward op of conv `c` on x -> y: the direct implicit GEMM, or the Winograd form for the layers listed above."""
@@ -404,13 +416,14 @@ class FasterRCNNEngine:
             return ("conv", d), d
         if c.wino_u is None:
             self._refresh_winograd([c.name])
-        T = nb * ((h + 1) // 2) * ((w + 1) // 2)
-        V = torch.empty(16, T, c.cin, dtype=torch.float32, device=self.dev)
-        M = torch.empty(16, T, c.cout, dtype=torch.float32, device=self.dev)
+        m = c.wino_m
+        T = nb * ((h + m - 1) // m) * ((w + m - 1) // m)
+        V = torch.empty((m + 2) ** 2, T, c.cin, dtype=torch.float32, device=self.dev)
+        M = torch.empty((m + 2) ** 2, T, c.cout, dtype=torch.float32, device=self.dev)
         keep += [V, M]
         op = ("wino", (x.data_ptr(), nb, h, w, c.cin, c.cout, V.data_ptr(), c.wino_u.data_ptr(), M.data_ptr(), T,
                        c.scale.data_ptr() if c.scale is not None else None, c.shift.data_ptr() if c.shift is not None else None,
-                       1 if relu else 0, y.data_ptr(), c.cout))
+                       1 if relu else 0, y.data_ptr(), c.cout, m))
         return op, d
 
     def _plan_base(self, nb, H, W, slot=0):
@@ -570,18 +583,18 @@ class FasterRCNNEngine:
                 o.p[0], o.p[1], o.p[2] = ptr(g), ptr(gs), ptr(out)
                 o.i[0], o.i[1], o.i[2], o.i[3] = m, n, ld, acc
             elif kind in ("wino", "wino_reuse"):
-                x, nb, hh, ww, c, n, V, U, M, T, scale, shift, act, y, ldy = p
+                x, nb, hh, ww, c, n, V, U, M, T, scale, shift, act, y, ldy, form = p
                 o.kind = L.OP_WINO if kind == "wino" else L.OP_WINO_REUSE
                 for j, v in enumerate((x, V, U, M, scale, shift, y)):
                     o.p[j] = ptr(v)
-                for j, v in enumerate((nb, hh, ww, c, n, T, act, ldy)):
+                for j, v in enumerate((nb, hh, ww, c, n, T, act, ldy, form)):
                     o.i[j] = v
             elif kind == "wino_wgrad":
-                dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, mode = p
+                dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, form, mode = p
                 o.kind = L.OP_WINO_WGRAD
                 for j, v in enumerate((dy, V, dZ, dU, dw)):
                     o.p[j] = ptr(v)
-                for j, v in enumerate((nb, hh, ww, c, n, ld_dy, T, ldw, mode)):
+                for j, v in enumerate((nb, hh, ww, c, n, ld_dy, T, ldw, mode, form)):
                     o.i[j] = v
             elif kind == "scatter":
                 src, nb, oh, ow, c, st, hh, ww, mask, dst = p
@@ -747,11 +760,12 @@ class FasterRCNNEngine:
         if op1[0] == "wino" and self.wino_wgrad:
             # dW in the Winograd domain on the V of the forward pass (F does not change between forward and backward)
             V, T = wino_keep[0], wino_keep[0].shape[1]
-            dZ = torch.empty(16, T, c1.cout, dtype=torch.float32, device=dev)
-            dU = torch.empty(16, c1.cin, c1.cout, dtype=torch.float32, device=dev)
+            P = (c1.wino_m + 2) ** 2
+            dZ = torch.empty(P, T, c1.cout, dtype=torch.float32, device=dev)
+            dU = torch.empty(P, c1.cin, c1.cout, dtype=torch.float32, device=dev)
             wino_keep += [dZ, dU]
             wg1 = ("wino_wgrad", [dh.data_ptr(), nb, fh, fw, c1.cin, c1.cout, 512, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T,
-                                  c1.dweight.data_ptr(), c1.ldw, 1])
+                                  c1.dweight.data_ptr(), c1.ldw, c1.wino_m, 1])
         else:
             wg1 = ("wgrad", b1)
         bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),

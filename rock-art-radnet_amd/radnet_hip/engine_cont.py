@@ -22,6 +22,9 @@ from .engine import RES_STAGES, Arena, FasterRCNNEngine
 
 class ContEngine(FasterRCNNEngine):
     supports_batched = False     # cont_train.py's step runs one image at a time (both optimizers move the shared stages)
+    # stages 3 / 4 train here: gradients flow through ten Winograd layers and Adam's first steps divide by |g| + 1e-7, so the
+    # 15x larger fp32 rounding of F(4x4,3x3) would show in the updates of small-gradient weights -- this mode keeps F(2x2,3x3)
+    WINOGRAD_F4_LAYERS = ()
 
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=2e-5, autotune=True):
         super().__init__(C_cfg, device_index, n_classes, bce_mode, lr, autotune)

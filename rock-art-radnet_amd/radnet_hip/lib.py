@@ -97,7 +97,7 @@ class TrainDesc(C.Structure):
                 ("rpn_refwd_ops", C.POINTER(Op)), ("n_rpn_refwd", _i),
                 ("pred", _vp), ("dz", _vp), ("ld_pred", _i), ("fh", _i), ("fw", _i), ("a", _i), ("bce_mode", _i), ("loss_scratch8", _vp), ("rpn_losses", _vp),
                 ("rpn_opt", AdamDesc), ("head_opt", AdamDesc), ("world", _i),
-                ("wino_w", _vp), ("wino_c", _i), ("wino_n", _i), ("wino_ldw", _i), ("wino_u", _vp),
+                ("wino_w", _vp), ("wino_c", _i), ("wino_n", _i), ("wino_ldw", _i), ("wino_form", _i), ("wino_u", _vp),
                 ("anchor_wh_host", C.POINTER(_d)), ("overlap_thresh", _d), ("max_boxes", _i),
                 ("R", _vp), ("Rp", _vp), ("Rn", _vp), ("prop_ws", _vp),
                 ("rw", _i), ("rh", _i), ("min_overlap", _d), ("max_overlap", _d), ("regr_std_host4", C.POINTER(_d)), ("bg_class", _i),
@@ -158,6 +158,11 @@ def load_library():
         "radnet_winograd_dy": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "radnet_wgrad_batched": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
         "radnet_winograd_filter_grad": (C.c_int, [vp, vp, i32, i32, i32, vp, i32]),
+        "radnet_winograd4_filter": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "radnet_winograd4_input": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+        "radnet_winograd4_output": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
+        "radnet_winograd4_dy": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+        "radnet_winograd4_filter_grad": (C.c_int, [vp, vp, i32, i32, i32, vp, i32]),
         "radnet_conv_wgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_colsum": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i32]),
         "radnet_maxpool_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),

@@ -144,6 +144,7 @@ class NativeTrainStep:
             c1 = eng.convs["rpn_conv1"]
             if c1.wino_u is not None:
                 d.wino_w, d.wino_c, d.wino_n, d.wino_ldw, d.wino_u = c1.weight.data_ptr(), c1.cin, c1.cout, c1.ldw, c1.wino_u.data_ptr()
+                d.wino_form = c1.wino_m
             d.anchor_wh_host = eng.anchor_wh.ctypes.data_as(C.POINTER(C.c_double))
             d.overlap_thresh, d.max_boxes = 0.7, 300
             d.R, d.Rp, d.Rn, d.prop_ws = rp["R"].data_ptr(), rp["Rp"].data_ptr(), rp["Rn"].data_ptr(), rp["prop_ws"].data_ptr()

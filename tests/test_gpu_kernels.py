@@ -489,10 +489,12 @@ def test_roi_targets_golden(ctx):
         assert np.allclose(got[:, 24:], ref[:, 24:], rtol=2e-7, atol=0)      # log: device vs NumPy, 1 ulp of fp64 -> <= 1 ulp fp32
 
 
-@pytest.mark.parametrize("case", [(1, 38, 63, 1024, 512), (20, 7, 7, 512, 512), (2, 9, 12, 64, 128)])
-def test_winograd_conv3x3_vs_oracle(ctx, case):
-    """Winograd F(2x2,3x3) path (filter / input transform, 16 batched GEMMs, output transform with the BN-ReLU epilogue)
-    against the oracle's direct 3x3 'same' convolution; odd sizes exercise the partial border tiles."""
+@pytest.mark.parametrize("form", [2, 4])
+@pytest.mark.parametrize("case", [(1, 38, 63, 1024, 512), (20, 7, 7, 512, 512), (2, 9, 12, 64, 128), (1, 75, 125, 128, 128), (1, 5, 3, 32, 64)])
+def test_winograd_conv3x3_vs_oracle(ctx, case, form):
+    """Winograd F(2x2,3x3) and F(4x4,3x3) paths (filter / input transform, 16 / 36 batched GEMMs, output transform with the
+    BN-ReLU epilogue) against the oracle's direct 3x3 'same' convolution at the suite's stated tolerance (2e-4 of the largest
+    value); sizes that are not multiples of the tile exercise the partial border tiles."""
     from oracle import dense
     nb, h, w, cin, cout = case
     rs = np.random.RandomState(sum(case))
@@ -501,25 +503,29 @@ def test_winograd_conv3x3_vs_oracle(ctx, case):
     sc = rs.uniform(0.5, 1.5, cout).astype(np.float32)
     sh = rs.standard_normal(cout).astype(np.float32)
     ref = np.maximum(dense.conv2d(x.astype(np.float64), wt.astype(np.float64), None, 1, (1, 1, 1, 1)) * sc + sh, 0)
-    T = nb * ((h + 1) // 2) * ((w + 1) // 2)
-    U = torch.empty(16, cin, cout, device="cuda")
-    V = torch.empty(16, T, cin, device="cuda")
-    M = torch.empty(16, T, cout, device="cuda")
+    T = nb * ((h + form - 1) // form) * ((w + form - 1) // form)
+    P, fn = (form + 2) ** 2, "radnet_winograd4_" if form == 4 else "radnet_winograd_"
+    U = torch.empty(P, cin, cout, device="cuda")
+    V = torch.full((P, T, cin), float("nan"), device="cuda")
+    M = torch.empty(P, T, cout, device="cuda")
     y = torch.full((nb, h, w, cout), float("nan"), device="cuda")
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     ctx.check(ctx.lib.radnet_set_workspace(ctx.h, ws.data_ptr(), ws.numel()), "ws")
-    ctx.call("radnet_winograd_filter", dev(wt.reshape(-1, cout)), cin, cout, cout, U)
-    ctx.call("radnet_winograd_input", dev(x), nb, h, w, cin, V)
-    ctx.call("radnet_gemm_batched", V, U, M, 16, T, cout, cin)
-    ctx.call("radnet_winograd_output", M, nb, h, w, cout, dev(sc), dev(sh), 1, y, cout)
+    ctx.call(fn + "filter", dev(wt.reshape(-1, cout)), cin, cout, cout, U)
+    ctx.call(fn + "input", dev(x), nb, h, w, cin, V)
+    ctx.call("radnet_gemm_batched", V, U, M, P, T, cout, cin)
+    ctx.call(fn + "output", M, nb, h, w, cout, dev(sc), dev(sh), 1, y, cout)
+    err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("winograd F(%dx%d) %s: max error %.2e of the largest activation" % (form, form, case, err))
     close(y.cpu().numpy(), ref)
     # the batched GEMM on its own
     mref = np.einsum("ptc,pcn->ptn", V.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
     close(M.cpu().numpy(), mref)
 
 
+@pytest.mark.parametrize("form", [2, 4])
 @pytest.mark.parametrize("case", [(1, 38, 63, 1024, 512), (2, 9, 11, 64, 128)])
-def test_winograd_wgrad_vs_oracle(ctx, case):
+def test_winograd_wgrad_vs_oracle(ctx, case, form):
     """Weight gradient of a 3x3 'same' conv in the Winograd domain (dy transform, 16 reduction-over-tiles GEMMs on the
     forward pass's transformed input, inverse filter transform) against the oracle's direct gradient."""
     from oracle import dense
@@ -530,17 +536,20 @@ def test_winograd_wgrad_vs_oracle(ctx, case):
     gs = rs.uniform(0.5, 1.5, cout).astype(np.float32)
     wt = np.zeros((3, 3, cin, cout), np.float32)
     _, dw_ref, _ = dense.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), (dy * gs).astype(np.float64), 1, (1, 1, 1, 1), need_dx=False)
-    T = nb * ((h + 1) // 2) * ((w + 1) // 2)
-    V = torch.empty(16, T, cin, device="cuda")
-    dZ = torch.empty(16, T, cout, device="cuda")
-    dU = torch.full((16, cin, cout), float("nan"), device="cuda")
+    T = nb * ((h + form - 1) // form) * ((w + form - 1) // form)
+    P, fn = (form + 2) ** 2, "radnet_winograd4_" if form == 4 else "radnet_winograd_"
+    V = torch.empty(P, T, cin, device="cuda")
+    dZ = torch.empty(P, T, cout, device="cuda")
+    dU = torch.full((P, cin, cout), float("nan"), device="cuda")
     dw = torch.full((9 * cin, cout), float("nan"), device="cuda")
-    ctx.call("radnet_winograd_input", dev(x), nb, h, w, cin, V)
-    ctx.call("radnet_winograd_dy", dev(dy), nb, h, w, cout, cout, dev(gs), dZ)
-    ctx.call("radnet_wgrad_batched", V, dZ, dU, 16, T, cin, cout, 0)
-    ctx.call("radnet_winograd_filter_grad", dU, cin, cout, cout, dw, 0)
+    ctx.call(fn + "input", dev(x), nb, h, w, cin, V)
+    ctx.call(fn + "dy", dev(dy), nb, h, w, cout, cout, dev(gs), dZ)
+    ctx.call("radnet_wgrad_batched", V, dZ, dU, P, T, cin, cout, 0)
+    ctx.call(fn + "filter_grad", dU, cin, cout, cout, dw, 0)
+    err = np.abs(dw.cpu().numpy() - dw_ref.reshape(-1, cout)).max() / np.abs(dw_ref).max()
+    print("winograd wgrad F(%dx%d) %s: max error %.2e of the largest gradient" % (form, form, case, err))
     close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
-    ctx.call("radnet_winograd_filter_grad", dU, cin, cout, cout, dw, 1)          # accumulate: doubles
+    ctx.call(fn + "filter_grad", dU, cin, cout, cout, dw, 1)          # accumulate: doubles
     close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
 
 

@@ -44,18 +44,26 @@ def main():
         d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.n = 3, 3, 1, 1, 1, cout
         d.ldw, d.ldy, d.ld_add, d.act, d.act_cols = cout, cout, cout, 1, 0
         t_dir = timeit(lambda: lib.radnet_conv_fwd(ctx.h, C.byref(d)))
-        T = nb * ((h + 1) // 2) * ((w + 1) // 2)
-        U = torch.empty(16, cin, cout, device="cuda")
-        V = torch.empty(16, T, cin, device="cuda")
-        M = torch.empty(16, T, cout, device="cuda")
-        t_f = timeit(lambda: lib.radnet_winograd_filter(ctx.h, wt.data_ptr(), cin, cout, cout, U.data_ptr()))
-        t_i = timeit(lambda: lib.radnet_winograd_input(ctx.h, x.data_ptr(), nb, h, w, cin, V.data_ptr()))
-        t_g = timeit(lambda: lib.radnet_gemm_batched(ctx.h, V.data_ptr(), U.data_ptr(), M.data_ptr(), 16, T, cout, cin))
-        t_o = timeit(lambda: lib.radnet_winograd_output(ctx.h, M.data_ptr(), nb, h, w, cout, sc.data_ptr(), sh.data_ptr(), 1, y.data_ptr(), cout))
         fl = 2.0 * nb * h * w * cout * 9 * cin
-        print("%-20s direct %6.1f us (%5.1f TF/s) | winograd in %5.1f + gemm %6.1f + out %5.1f = %6.1f us (%5.1f TF/s eff.), filter %5.1f us; %d tiles" % (
-            name, t_dir, fl / t_dir / 1e6, t_i, t_g, t_o, t_i + t_g + t_o, fl / (t_i + t_g + t_o) / 1e6, t_f, T))
-
+        line = "%-20s direct %6.1f us (%5.1f TF/s)" % (name, t_dir, fl / t_dir / 1e6)
+        for form in (2, 4):
+            fn = "radnet_winograd4_" if form == 4 else "radnet_winograd_"
+            P, T = (form + 2) ** 2, nb * ((h + form - 1) // form) * ((w + form - 1) // form)
+            U = torch.empty(P, cin, cout, device="cuda")
+            V = torch.empty(P, T, cin, device="cuda")
+            M = torch.empty(P, T, cout, device="cuda")
+            dU = torch.empty(P, cin, cout, device="cuda")
+            dw = torch.empty(9 * cin, cout, device="cuda")
+            t_f = timeit(lambda: getattr(lib, fn + "filter")(ctx.h, wt.data_ptr(), cin, cout, cout, U.data_ptr()))
+            t_i = timeit(lambda: getattr(lib, fn + "input")(ctx.h, x.data_ptr(), nb, h, w, cin, V.data_ptr()))
+            t_g = timeit(lambda: lib.radnet_gemm_batched(ctx.h, V.data_ptr(), U.data_ptr(), M.data_ptr(), P, T, cout, cin))
+            t_o = timeit(lambda: getattr(lib, fn + "output")(ctx.h, M.data_ptr(), nb, h, w, cout, sc.data_ptr(), sh.data_ptr(), 1, y.data_ptr(), cout))
+            t_dz = timeit(lambda: getattr(lib, fn + "dy")(ctx.h, y.data_ptr(), nb, h, w, cout, cout, None, M.data_ptr()))
+            t_wg = timeit(lambda: lib.radnet_wgrad_batched(ctx.h, V.data_ptr(), M.data_ptr(), dU.data_ptr(), P, T, cin, cout, 0))
+            t_fg = timeit(lambda: getattr(lib, fn + "filter_grad")(ctx.h, dU.data_ptr(), cin, cout, cout, dw.data_ptr(), 0))
+            line += "\n    F(%dx%d): in %5.1f + gemm %6.1f + out %5.1f = %6.1f us (%5.1f TF/s eff.), filter %5.1f us; %d tiles | wgrad: dy %5.1f + gemm %6.1f + filter-grad %5.1f = %6.1f us" % (
+                form, form, t_i, t_g, t_o, t_i + t_g + t_o, fl / (t_i + t_g + t_o) / 1e6, t_f, T, t_dz, t_wg, t_fg, t_dz + t_wg + t_fg)
+        print(line, flush=True)
 
 if __name__ == "__main__":
     main()
