@@ -229,72 +229,80 @@ __global__ void __launch_bounds__(256) wino_filter_grad_kernel(const float* __re
 // The transforms multiply by up to 8 and by 1/24: against the fp64 direct sum the fp32 result is off by about 2e-5 of the
 // largest activation at C = 1024 (F(2x2): 1e-6, direct fp32: 5e-7) -- inside the 2e-4 the kernel tests state.
 // Layouts as above with 36 positions p = 6*xi + nu and tiles of 4x4 outputs (input rows 4ti-1 .. 4ti+4).
-__device__ __forceinline__ float4 f4s(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float4 f4fma(float4 a, float s, float4 b) { return make_float4(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z), fmaf(a.w, s, b.w)); }
+// Kernels are templates over the per-thread channel vector (instantiated for float4, see RADNET_WINO4_LAUNCH).
+template <typename VT> __device__ __forceinline__ VT vzero();
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
+template <> __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float vmax0(float a) { return fmaxf(a, 0.f); }
+__device__ __forceinline__ float2 vmax0(float2 a) { return make_float2(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f)); }
+__device__ __forceinline__ float4 vmax0(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
 
-__device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&o)[6]) {          // o = B^T d
-  o[0] = f4fma(d[0], 4.f, f4fma(d[2], -5.f, d[4]));
-  const float4 p = f4fma(d[2], -4.f, d[4]), q = f4fma(d[1], -4.f, d[3]);
-  o[1] = f4add(p, q);
-  o[2] = f4sub(p, q);
-  const float4 r = f4sub(d[4], d[2]), t = f4s(f4sub(d[3], d[1]), 2.f);
-  o[3] = f4add(r, t);
-  o[4] = f4sub(r, t);
-  o[5] = f4fma(d[1], 4.f, f4fma(d[3], -5.f, d[5]));
+template <typename VT> __device__ __forceinline__ void bt6(const VT (&d)[6], VT (&o)[6]) {          // o = B^T d
+  o[0] = d[0] * 4.f + (d[4] - d[2] * 5.f);
+  const VT p = d[4] - d[2] * 4.f, q = d[3] - d[1] * 4.f;
+  o[1] = p + q;
+  o[2] = p - q;
+  const VT r = d[4] - d[2], t = (d[3] - d[1]) * 2.f;
+  o[3] = r + t;
+  o[4] = r - t;
+  o[5] = d[1] * 4.f + (d[5] - d[3] * 5.f);
 }
-__device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&o)[4]) {          // o = A^T m
-  const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]), s34 = f4add(m[3], m[4]), d34 = f4sub(m[3], m[4]);
-  o[0] = f4add(f4add(m[0], s12), s34);
-  o[1] = f4fma(d34, 2.f, d12);
-  o[2] = f4fma(s34, 4.f, s12);
-  o[3] = f4add(f4fma(d34, 8.f, d12), m[5]);
+template <typename VT> __device__ __forceinline__ void at6(const VT (&m)[6], VT (&o)[4]) {          // o = A^T m
+  const VT s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = (m[0] + s12) + s34;
+  o[1] = d34 * 2.f + d12;
+  o[2] = s34 * 4.f + s12;
+  o[3] = (d34 * 8.f + d12) + m[5];
 }
-__device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&z)[6]) {           // z = A y (adjoint of at6)
-  const float4 e = f4add(y[0], y[2]), o = f4add(y[1], y[3]);
-  const float4 e4 = f4fma(y[2], 4.f, y[0]), o2 = f4fma(y[3], 8.f, f4s(y[1], 2.f));
+template <typename VT> __device__ __forceinline__ void a6(const VT (&y)[4], VT (&z)[6]) {           // z = A y (adjoint of at6)
+  const VT e = y[0] + y[2], o = y[1] + y[3];
+  const VT e4 = y[2] * 4.f + y[0], o2 = y[3] * 8.f + y[1] * 2.f;
   z[0] = y[0];
-  z[1] = f4add(e, o);
-  z[2] = f4sub(e, o);
-  z[3] = f4add(e4, o2);
-  z[4] = f4sub(e4, o2);
+  z[1] = e + o;
+  z[2] = e - o;
+  z[3] = e4 + o2;
+  z[4] = e4 - o2;
   z[5] = y[3];
 }
-__device__ __forceinline__ void g6(const float4 (&g)[3], float4 (&u)[6]) {           // u = G g
-  const float4 s = f4add(g[0], g[2]);
-  u[0] = f4s(g[0], 0.25f);
-  u[1] = f4s(f4add(s, g[1]), -1.f / 6.f);
-  u[2] = f4s(f4sub(s, g[1]), -1.f / 6.f);
-  const float4 a = f4fma(g[0], 1.f / 24.f, f4s(g[2], 1.f / 6.f)), b = f4s(g[1], 1.f / 12.f);
-  u[3] = f4add(a, b);
-  u[4] = f4sub(a, b);
+template <typename VT> __device__ __forceinline__ void g6(const VT (&g)[3], VT (&u)[6]) {           // u = G g
+  const VT s = g[0] + g[2];
+  u[0] = g[0] * 0.25f;
+  u[1] = (s + g[1]) * (-1.f / 6.f);
+  u[2] = (s - g[1]) * (-1.f / 6.f);
+  const VT a = g[0] * (1.f / 24.f) + g[2] * (1.f / 6.f), b = g[1] * (1.f / 12.f);
+  u[3] = a + b;
+  u[4] = a - b;
   u[5] = g[2];
 }
-__device__ __forceinline__ void gt6(const float4 (&u)[6], float4 (&w)[3]) {          // w = G^T u (adjoint of g6)
-  const float4 s12 = f4add(u[1], u[2]), s34 = f4add(u[3], u[4]);
-  w[0] = f4fma(u[0], 0.25f, f4fma(s12, -1.f / 6.f, f4s(s34, 1.f / 24.f)));
-  w[1] = f4fma(f4sub(u[2], u[1]), 1.f / 6.f, f4s(f4sub(u[3], u[4]), 1.f / 12.f));
-  w[2] = f4add(f4fma(s12, -1.f / 6.f, f4s(s34, 1.f / 6.f)), u[5]);
+template <typename VT> __device__ __forceinline__ void gt6(const VT (&u)[6], VT (&w)[3]) {          // w = G^T u (adjoint of g6)
+  const VT s12 = u[1] + u[2], s34 = u[3] + u[4];
+  w[0] = u[0] * 0.25f + (s12 * (-1.f / 6.f) + s34 * (1.f / 24.f));
+  w[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+  w[2] = (s12 * (-1.f / 6.f) + s34 * (1.f / 6.f)) + u[5];
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restrict__ g, int C, int N, int ldw, float* __restrict__ U) {
-  const int n4 = N >> 2;
-  const long long total = (long long)C * n4, ps = total;
+  constexpr int W = sizeof(VT) / 4;
+  const int nv = N / W;
+  const long long total = (long long)C * nv, ps = total;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
-    float4 t[6][3];
+    const int c = (int)(i / nv), nq = (int)(i - (long long)c * nv);
+    VT t[6][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      float4 col[3], o[6];
+      VT col[3], o[6];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) col[a] = *reinterpret_cast<const float4*>(g + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
+      for (int a = 0; a < 3; ++a) col[a] = *reinterpret_cast<const VT*>(g + ((long long)(a * 3 + b) * C + c) * ldw + nq * W);
       g6(col, o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) t[a][b] = o[a];
     }
-    float4* dst = reinterpret_cast<float4*>(U) + (long long)c * n4 + nq;
+    VT* dst = reinterpret_cast<VT*>(U) + (long long)c * nv + nq;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float4 o[6];
+      VT o[6];
       g6(t[a], o);
 #pragma unroll
       for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
@@ -302,36 +310,38 @@ __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) wino4_input_kernel(const float* __restrict__ x, int nb, int H, int W, int C, int TH, int TW,
+template <typename VT>
+__global__ void __launch_bounds__(256) wino4_input_kernel(const float* __restrict__ x, int nb, int H, int W_, int C, int TH, int TW,
                                                           float* __restrict__ V) {
-  const int c4 = C >> 2;
-  const long long T = (long long)nb * TH * TW, total = T * c4, ps = total;
+  constexpr int W = sizeof(VT) / 4;
+  const int cv = C / W;
+  const long long T = (long long)nb * TH * TW, total = T * cv, ps = total;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4);
-    const long long tile = i / c4;
+    const int cq = (int)(i % cv);
+    const long long tile = i / cv;
     const int tj = (int)(tile % TW);
     const int ti = (int)((tile / TW) % TH);
     const int img = (int)(tile / ((long long)TW * TH));
-    float4 t[6][6];
+    VT t[6][6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       const int iw = 4 * tj - 1 + b;
-      float4 col[6], o[6];
+      VT col[6], o[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int ih = 4 * ti - 1 + a;
-        col[a] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-                     ? *reinterpret_cast<const float4*>(x + (((long long)img * H + ih) * W + iw) * C + cq * 4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        col[a] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W_)
+                     ? *reinterpret_cast<const VT*>(x + (((long long)img * H + ih) * W_ + iw) * C + cq * W)
+                     : vzero<VT>();
       }
       bt6(col, o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) t[a][b] = o[a];
     }
-    float4* dst = reinterpret_cast<float4*>(V) + tile * c4 + cq;
+    VT* dst = reinterpret_cast<VT*>(V) + tile * cv + cq;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float4 o[6];
+      VT o[6];
       bt6(t[a], o);
 #pragma unroll
       for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
@@ -339,79 +349,85 @@ __global__ void __launch_bounds__(256) wino4_input_kernel(const float* __restric
   }
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) wino4_output_kernel(const float* __restrict__ Mm, int nb, int OH, int OW, int N, int TH, int TW,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                            float* __restrict__ y, int ldy) {
-  const int n4 = N >> 2;
-  const long long T = (long long)nb * TH * TW, total = T * n4, ps = total;
+  constexpr int W = sizeof(VT) / 4;
+  const int nv = N / W;
+  const long long T = (long long)nb * TH * TW, total = T * nv, ps = total;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % n4);
-    const long long tile = i / n4;
+    const int nq = (int)(i % nv);
+    const long long tile = i / nv;
     const int tj = (int)(tile % TW);
     const int ti = (int)((tile / TW) % TH);
     const int img = (int)(tile / ((long long)TW * TH));
-    const float4* src = reinterpret_cast<const float4*>(Mm) + tile * n4 + nq;
-    float4 t[4][6];
+    const VT* src = reinterpret_cast<const VT*>(Mm) + tile * nv + nq;
+    VT t[4][6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-      float4 col[6], o[4];
+      VT col[6], o[4];
 #pragma unroll
       for (int a = 0; a < 6; ++a) col[a] = src[(6 * a + b) * ps];
       at6(col, o);
 #pragma unroll
       for (int a = 0; a < 4; ++a) t[a][b] = o[a];
     }
-    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + nq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    VT sc, sh = vzero<VT>();
+    if (scale) sc = *reinterpret_cast<const VT*>(scale + nq * W);
+    if (shift) sh = *reinterpret_cast<const VT*>(shift + nq * W);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int oh = 4 * ti + a;
-      float4 o[4];
+      VT o[4];
       at6(t[a], o);
       if (oh >= OH) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int ow = 4 * tj + b;
         if (ow >= OW) continue;
-        float4 v = make_float4(fmaf(o[b].x, sc.x, sh.x), fmaf(o[b].y, sc.y, sh.y), fmaf(o[b].z, sc.z, sh.z), fmaf(o[b].w, sc.w, sh.w));
-        if (act == 1) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        *reinterpret_cast<float4*>(y + (((long long)img * OH + oh) * OW + ow) * ldy + nq * 4) = v;
+        VT v = scale ? o[b] * sc + sh : o[b] + sh;
+        if (act == 1) v = vmax0(v);
+        *reinterpret_cast<VT*>(y + (((long long)img * OH + oh) * OW + ow) * ldy + nq * W) = v;
       }
     }
   }
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__ dy, int nb, int OH, int OW, int N, int ld_dy, int TH, int TW,
                                                        const float* __restrict__ gscale, float* __restrict__ dZ) {
-  const int n4 = N >> 2;
-  const long long T = (long long)nb * TH * TW, total = T * n4, ps = total;
+  constexpr int W = sizeof(VT) / 4;
+  const int nv = N / W;
+  const long long T = (long long)nb * TH * TW, total = T * nv, ps = total;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % n4);
-    const long long tile = i / n4;
+    const int nq = (int)(i % nv);
+    const long long tile = i / nv;
     const int tj = (int)(tile % TW);
     const int ti = (int)((tile / TW) % TH);
     const int img = (int)(tile / ((long long)TW * TH));
-    const float4 gs = gscale ? *reinterpret_cast<const float4*>(gscale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 r[6][4];
+    VT gs;
+    if (gscale) gs = *reinterpret_cast<const VT*>(gscale + nq * W);
+    VT r[6][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int ow = 4 * tj + b;
-      float4 col[4], o[6];
+      VT col[4], o[6];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int oh = 4 * ti + a;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (oh < OH && ow < OW) v = *reinterpret_cast<const float4*>(dy + (((long long)img * OH + oh) * OW + ow) * ld_dy + nq * 4);
-        col[a] = make_float4(v.x * gs.x, v.y * gs.y, v.z * gs.z, v.w * gs.w);
+        VT v = vzero<VT>();
+        if (oh < OH && ow < OW) v = *reinterpret_cast<const VT*>(dy + (((long long)img * OH + oh) * OW + ow) * ld_dy + nq * W);
+        col[a] = gscale ? v * gs : v;
       }
       a6(col, o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) r[a][b] = o[a];
     }
-    float4* dst = reinterpret_cast<float4*>(dZ) + tile * n4 + nq;
+    VT* dst = reinterpret_cast<VT*>(dZ) + tile * nv + nq;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float4 o[6];
+      VT o[6];
       a6(r[a], o);
 #pragma unroll
       for (int b = 0; b < 6; ++b) dst[(6 * a + b) * ps] = o[b];
@@ -419,16 +435,18 @@ __global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__
   }
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) wino4_filter_grad_kernel(const float* __restrict__ dU, int C, int N, int ldw, float* __restrict__ dw, int accumulate) {
-  const int n4 = N >> 2;
-  const long long total = (long long)C * n4, ps = total;
+  constexpr int W = sizeof(VT) / 4;
+  const int nv = N / W;
+  const long long total = (long long)C * nv, ps = total;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
-    const float4* src = reinterpret_cast<const float4*>(dU) + (long long)c * n4 + nq;
-    float4 t[3][6];
+    const int c = (int)(i / nv), nq = (int)(i - (long long)c * nv);
+    const VT* src = reinterpret_cast<const VT*>(dU) + (long long)c * nv + nq;
+    VT t[3][6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-      float4 col[6], o[3];
+      VT col[6], o[3];
 #pragma unroll
       for (int a = 0; a < 6; ++a) col[a] = src[(6 * a + b) * ps];
       gt6(col, o);
@@ -437,16 +455,22 @@ __global__ void __launch_bounds__(256) wino4_filter_grad_kernel(const float* __r
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      float4 o[3];
+      VT o[3];
       gt6(t[a], o);
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        float4* q = reinterpret_cast<float4*>(dw + ((long long)(a * 3 + b) * C + c) * ldw + nq * 4);
-        *q = accumulate ? f4add(*q, o[b]) : o[b];
+        VT* q = reinterpret_cast<VT*>(dw + ((long long)(a * 3 + b) * C + c) * ldw + nq * W);
+        *q = accumulate ? *q + o[b] : o[b];
       }
     }
   }
 }
+
+// One thread per (tile | filter element, 4 channels).  Narrower per-thread vectors (float2 / float: 2x / 4x the workgroups for
+// the 160-tile stage-4 layers) were measured and changed nothing -- input transform 6.3 us, output 5.9 us either way: at a few
+// MB per launch these kernels last one launch + one memory round trip, not a bandwidth- or occupancy-limited time.
+#define RADNET_WINO4_LAUNCH(kernel, units4, ...) \
+  hipLaunchKernelGGL((kernel<float4>), dim3(grid_of(units4)), dim3(256), 0, ctx->stream, __VA_ARGS__)
 
 inline int grid_of(long long total) {
   long long b = (total + 255) / 256;
@@ -507,7 +531,7 @@ extern "C" int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int
 extern "C" int radnet_winograd4_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u) {
   if (!ctx || !w || !u) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter: n=%d, ldw=%d must be multiples of 4", n, ldw);
-  hipLaunchKernelGGL(wino4_filter_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, w, c, n, ldw, u);
+  RADNET_WINO4_LAUNCH(wino4_filter_kernel, (long long)c * (n / 4), w, c, n, ldw, u);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_filter");
   return RADNET_OK;
 }
@@ -516,7 +540,7 @@ extern "C" int radnet_winograd4_input(radnet_ctx* ctx, const float* x, int32_t n
   if (!ctx || !x || !v) return RADNET_ERR_ARG;
   if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_input: c=%d must be a multiple of 4", c);
   const int th = (h + 3) / 4, tw = (w + 3) / 4;
-  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_of((long long)nb * th * tw * (c / 4))), dim3(256), 0, ctx->stream, x, nb, h, w, c, th, tw, v);
+  RADNET_WINO4_LAUNCH(wino4_input_kernel, (long long)nb * th * tw * (c / 4), x, nb, h, w, c, th, tw, v);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_input");
   return RADNET_OK;
 }
@@ -526,8 +550,7 @@ extern "C" int radnet_winograd4_output(radnet_ctx* ctx, const float* m, int32_t 
   if (!ctx || !m || !y) return RADNET_ERR_ARG;
   if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_output: n=%d, ldy=%d", n, ldy);
   const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
-  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, m, nb, oh, ow, n, th, tw, scale,
-                     shift, act, y, ldy);
+  RADNET_WINO4_LAUNCH(wino4_output_kernel, (long long)nb * th * tw * (n / 4), m, nb, oh, ow, n, th, tw, scale, shift, act, y, ldy);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_output");
   return RADNET_OK;
 }
@@ -537,8 +560,7 @@ extern "C" int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb,
   if (!ctx || !dy || !dz) return RADNET_ERR_ARG;
   if ((n & 3) || (ld_dy & 3) || ld_dy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_dy: n=%d, ld_dy=%d", n, ld_dy);
   const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
-  hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, dy, nb, oh, ow, n, ld_dy, th, tw,
-                     gscale, dz);
+  RADNET_WINO4_LAUNCH(wino4_dy_kernel, (long long)nb * th * tw * (n / 4), dy, nb, oh, ow, n, ld_dy, th, tw, gscale, dz);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_dy");
   return RADNET_OK;
 }
@@ -546,7 +568,7 @@ extern "C" int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb,
 extern "C" int radnet_winograd4_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate) {
   if (!ctx || !du || !dw) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter_grad: n=%d, ldw=%d must be multiples of 4", n, ldw);
-  hipLaunchKernelGGL(wino4_filter_grad_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, du, c, n, ldw, dw, accumulate ? 1 : 0);
+  RADNET_WINO4_LAUNCH(wino4_filter_grad_kernel, (long long)c * (n / 4), du, c, n, ldw, dw, accumulate ? 1 : 0);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_filter_grad");
   return RADNET_OK;
 }
