@@ -20,13 +20,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int nb, int h, int w,
                                                       int c4, int oh, int ow, int k, int s) {
   const long long total = (long long)nb * oh * ow * c4;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    int cc = (int)(idx % c4);
-    long long p = idx / c4;
-    int ox = (int)(p % ow);
-    p /= ow;
-    int oy = (int)(p % oh);
-    int b = (int)(p / oh);
+  // 32-bit index arithmetic (the launcher rejects >= 2^31 work items): a 64-bit division is a long software routine
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
+    unsigned p = idx / (unsigned)c4;
+    int cc = (int)(idx - p * (unsigned)c4);
+    unsigned q = p / (unsigned)ow;
+    int ox = (int)(p - q * (unsigned)ow);
+    int b = (int)(q / (unsigned)oh);
+    int oy = (int)(q - (unsigned)b * (unsigned)oh);
     const float4* src = reinterpret_cast<const float4*>(x) + ((long long)(b * h + oy * s) * w + ox * s) * c4 + cc;
     float4 m = src[0];
     for (int i = 0; i < k; ++i)
@@ -129,9 +130,9 @@ __global__ void __launch_bounds__(256) avgpool_bwd_relu_kernel(const float* __re
                                                                int r, int hw, int c4, float* __restrict__ dx) {
   const long long total = (long long)r * hw * c4;
   const float inv = (float)hw;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    int cc = (int)(idx % c4);
-    int rr = (int)(idx / ((long long)hw * c4));
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    int cc = (int)(idx % (unsigned)c4);
+    int rr = (int)(idx / ((unsigned)hw * (unsigned)c4));
     float4 g = reinterpret_cast<const float4*>(dfeat)[(long long)rr * c4 + cc];
     float4 a = reinterpret_cast<const float4*>(yact)[idx];
     float4 o;
@@ -464,6 +465,7 @@ extern "C" int radnet_maxpool_fwd(radnet_ctx* ctx, const float* x, float* y, int
   const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
   if (oh <= 0 || ow <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "maxpool: empty output");
   const long long total = (long long)nb * oh * ow * (c / 4);
+  if (total >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "maxpool: %lld work items (32-bit index arithmetic)", total);
   hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, y, nb, h, w, c / 4, oh, ow, k, s);
   RADNET_CHECK_LAUNCH(ctx, "maxpool");
   return RADNET_OK;
@@ -498,6 +500,7 @@ extern "C" int radnet_avgpool_fwd(radnet_ctx* ctx, const float* x, int32_t r, in
 extern "C" int radnet_avgpool_bwd_relu(radnet_ctx* ctx, const float* dfeat, const float* y_act, int32_t r, int32_t hw, int32_t c, float* dx) {
   if (!ctx || !dfeat || !y_act || !dx) return RADNET_ERR_ARG;
   if (c % 4) RADNET_FAIL(ctx, RADNET_ERR_ARG, "avgpool_bwd: c %% 4");
+  if ((long long)r * hw * (c / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "avgpool_bwd: too many work items (32-bit index arithmetic)");
   hipLaunchKernelGGL(avgpool_bwd_relu_kernel, dim3(grid_for((long long)r * hw * (c / 4))), dim3(256), 0, ctx->stream, dfeat, y_act, r, hw,
                      c / 4, dx);
   RADNET_CHECK_LAUNCH(ctx, "avgpool_bwd_relu");
@@ -603,13 +606,13 @@ namespace {
 __global__ void __launch_bounds__(256) scatter_strided_kernel(const float4* __restrict__ src, int nb, int oh, int ow, int c4, int s, int h, int w,
                                                               const float4* __restrict__ mask, float4* __restrict__ dst) {
   const long long total = (long long)nb * h * w * c4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % c4);
-    long long p = i / c4;
-    const int iw = (int)(p % w);
-    p /= w;
-    const int ih = (int)(p % h);
-    const int img = (int)(p / h);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned p = i / (unsigned)c4;
+    const int cc = (int)(i - p * (unsigned)c4);
+    const unsigned q = p / (unsigned)w;
+    const int iw = (int)(p - q * (unsigned)w);
+    const int img = (int)(q / (unsigned)h);
+    const int ih = (int)(q - (unsigned)img * (unsigned)h);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int qh = ih / s, qw = iw / s;
     if (qh * s == ih && qw * s == iw && qh < oh && qw < ow) v = src[(((long long)img * oh + qh) * ow + qw) * c4 + cc];
@@ -628,6 +631,7 @@ extern "C" int radnet_scatter_strided(radnet_ctx* ctx, const float* src, int32_t
   if (c % 4 || stride < 1 || (oh - 1) * stride >= h || (ow - 1) * stride >= w)
     RADNET_FAIL(ctx, RADNET_ERR_ARG, "scatter_strided: c=%d stride=%d grid %dx%d into %dx%d", c, stride, oh, ow, h, w);
   const long long total = (long long)nb * h * w * (c / 4);
+  if (total >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "scatter_strided: %lld work items (32-bit index arithmetic)", total);
   hipLaunchKernelGGL(scatter_strided_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ctx->stream, (const float4*)src, nb, oh, ow, c / 4,
                      stride, h, w, (const float4*)mask, (float4*)dst);
   RADNET_CHECK_LAUNCH(ctx, "scatter_strided");

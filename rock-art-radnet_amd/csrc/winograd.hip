@@ -23,8 +23,8 @@ __device__ __forceinline__ float4 f4half(float4 a) { return make_float4(0.5f * a
 __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ g, int C, int N, int ldw, float* __restrict__ U) {
   const int n4 = N >> 2;
   const long long total = (long long)C * n4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const int c = (int)(i / (unsigned)n4), nq = (int)(i - (unsigned)c * (unsigned)n4);
     float4 w[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -55,12 +55,13 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
                                                          float* __restrict__ V) {
   const int c4 = C >> 2;
   const long long T = (long long)nb * TH * TW, total = T * c4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4);
-    const long long tile = i / c4;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)c4;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int cq = (int)(i - tile * (unsigned)c4);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     float4 d[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -100,12 +101,13 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                                                           float* __restrict__ y, int ldy) {
   const int n4 = N >> 2;
   const long long T = (long long)nb * TH * TW, total = T * n4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % n4);
-    const long long tile = i / n4;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)n4;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int nq = (int)(i - tile * (unsigned)n4);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     const long long ps = T * n4;
     const float4* src = reinterpret_cast<const float4*>(Mm) + tile * n4 + nq;
     float4 m[4][4];
@@ -148,12 +150,13 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gscale, float* __restrict__ dZ) {
   const int n4 = N >> 2;
   const long long T = (long long)nb * TH * TW, total = T * n4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % n4);
-    const long long tile = i / n4;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)n4;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int nq = (int)(i - tile * (unsigned)n4);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     const float4 gs = gscale ? *reinterpret_cast<const float4*>(gscale + nq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
     float4 d[2][2];
 #pragma unroll
@@ -190,8 +193,8 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 __global__ void __launch_bounds__(256) wino_filter_grad_kernel(const float* __restrict__ dU, int C, int N, int ldw, float* __restrict__ dw, int accumulate) {
   const int n4 = N >> 2;
   const long long total = (long long)C * n4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / n4), nq = (int)(i - (long long)c * n4);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const int c = (int)(i / (unsigned)n4), nq = (int)(i - (unsigned)c * (unsigned)n4);
     const long long ps = (long long)C * n4;
     const float4* src = reinterpret_cast<const float4*>(dU) + (long long)c * n4 + nq;
     float4 u[4][4];
@@ -287,8 +290,8 @@ __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restri
   constexpr int W = sizeof(VT) / 4;
   const int nv = N / W;
   const long long total = (long long)C * nv, ps = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / nv), nq = (int)(i - (long long)c * nv);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const int c = (int)(i / (unsigned)nv), nq = (int)(i - (unsigned)c * (unsigned)nv);
     VT t[6][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -316,12 +319,13 @@ __global__ void __launch_bounds__(256) wino4_input_kernel(const float* __restric
   constexpr int W = sizeof(VT) / 4;
   const int cv = C / W;
   const long long T = (long long)nb * TH * TW, total = T * cv, ps = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % cv);
-    const long long tile = i / cv;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)cv;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int cq = (int)(i - tile * (unsigned)cv);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     VT t[6][6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -356,12 +360,13 @@ __global__ void __launch_bounds__(256) wino4_output_kernel(const float* __restri
   constexpr int W = sizeof(VT) / 4;
   const int nv = N / W;
   const long long T = (long long)nb * TH * TW, total = T * nv, ps = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % nv);
-    const long long tile = i / nv;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)nv;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int nq = (int)(i - tile * (unsigned)nv);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     const VT* src = reinterpret_cast<const VT*>(Mm) + tile * nv + nq;
     VT t[4][6];
 #pragma unroll
@@ -400,12 +405,13 @@ __global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__
   constexpr int W = sizeof(VT) / 4;
   const int nv = N / W;
   const long long T = (long long)nb * TH * TW, total = T * nv, ps = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nq = (int)(i % nv);
-    const long long tile = i / nv;
-    const int tj = (int)(tile % TW);
-    const int ti = (int)((tile / TW) % TH);
-    const int img = (int)(tile / ((long long)TW * TH));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const unsigned tile = i / (unsigned)nv;                     // 32-bit index arithmetic: 64-bit divisions cost microseconds here
+    const int nq = (int)(i - tile * (unsigned)nv);
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
     VT gs;
     if (gscale) gs = *reinterpret_cast<const VT*>(gscale + nq * W);
     VT r[6][4];
@@ -440,8 +446,8 @@ __global__ void __launch_bounds__(256) wino4_filter_grad_kernel(const float* __r
   constexpr int W = sizeof(VT) / 4;
   const int nv = N / W;
   const long long total = (long long)C * nv, ps = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i / nv), nq = (int)(i - (long long)c * nv);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {      // total < 2^31 (launcher)
+    const int c = (int)(i / (unsigned)nv), nq = (int)(i - (unsigned)c * (unsigned)nv);
     const VT* src = reinterpret_cast<const VT*>(dU) + (long long)c * nv + nq;
     VT t[3][6];
 #pragma unroll
@@ -482,6 +488,7 @@ inline int grid_of(long long total) {
 extern "C" int radnet_winograd_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u) {
   if (!ctx || !w || !u) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_filter: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  if ((long long)c * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino_filter_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)c * (n / 4)));
   hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, w, c, n, ldw, u);
   RADNET_CHECK_LAUNCH(ctx, "winograd_filter");
   return RADNET_OK;
@@ -491,6 +498,7 @@ extern "C" int radnet_winograd_input(radnet_ctx* ctx, const float* x, int32_t nb
   if (!ctx || !x || !v) return RADNET_ERR_ARG;
   if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_input: c=%d must be a multiple of 4", c);
   const int th = (h + 1) / 2, tw = (w + 1) / 2;
+  if ((long long)nb * th * tw * (c / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino_input_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (c / 4)));
   hipLaunchKernelGGL(wino_input_kernel, dim3(grid_of((long long)nb * th * tw * (c / 4))), dim3(256), 0, ctx->stream, x, nb, h, w, c, th, tw, v);
   RADNET_CHECK_LAUNCH(ctx, "winograd_input");
   return RADNET_OK;
@@ -501,6 +509,7 @@ extern "C" int radnet_winograd_output(radnet_ctx* ctx, const float* m, int32_t n
   if (!ctx || !m || !y) return RADNET_ERR_ARG;
   if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_output: n=%d, ldy=%d", n, ldy);
   const int th = (oh + 1) / 2, tw = (ow + 1) / 2;
+  if ((long long)nb * th * tw * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino_output_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (n / 4)));
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, m, nb, oh, ow, n, th, tw, scale,
                      shift, act, y, ldy);
   RADNET_CHECK_LAUNCH(ctx, "winograd_output");
@@ -512,6 +521,7 @@ extern "C" int radnet_winograd_dy(radnet_ctx* ctx, const float* dy, int32_t nb, 
   if (!ctx || !dy || !dz) return RADNET_ERR_ARG;
   if ((n & 3) || (ld_dy & 3) || ld_dy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_dy: n=%d, ld_dy=%d", n, ld_dy);
   const int th = (oh + 1) / 2, tw = (ow + 1) / 2;
+  if ((long long)nb * th * tw * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino_dy_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (n / 4)));
   hipLaunchKernelGGL(wino_dy_kernel, dim3(grid_of((long long)nb * th * tw * (n / 4))), dim3(256), 0, ctx->stream, dy, nb, oh, ow, n, ld_dy, th, tw,
                      gscale, dz);
   RADNET_CHECK_LAUNCH(ctx, "winograd_dy");
@@ -521,6 +531,7 @@ extern "C" int radnet_winograd_dy(radnet_ctx* ctx, const float* dy, int32_t nb, 
 extern "C" int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate) {
   if (!ctx || !du || !dw) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd_filter_grad: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  if ((long long)c * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino_filter_grad_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)c * (n / 4)));
   hipLaunchKernelGGL(wino_filter_grad_kernel, dim3(grid_of((long long)c * (n / 4))), dim3(256), 0, ctx->stream, du, c, n, ldw, dw, accumulate ? 1 : 0);
   RADNET_CHECK_LAUNCH(ctx, "winograd_filter_grad");
   return RADNET_OK;
@@ -531,6 +542,7 @@ extern "C" int radnet_winograd_filter_grad(radnet_ctx* ctx, const float* du, int
 extern "C" int radnet_winograd4_filter(radnet_ctx* ctx, const float* w, int32_t c, int32_t n, int32_t ldw, float* u) {
   if (!ctx || !w || !u) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  if ((long long)c * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_filter_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)c * (n / 4)));
   RADNET_WINO4_LAUNCH(wino4_filter_kernel, (long long)c * (n / 4), w, c, n, ldw, u);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_filter");
   return RADNET_OK;
@@ -540,6 +552,7 @@ extern "C" int radnet_winograd4_input(radnet_ctx* ctx, const float* x, int32_t n
   if (!ctx || !x || !v) return RADNET_ERR_ARG;
   if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_input: c=%d must be a multiple of 4", c);
   const int th = (h + 3) / 4, tw = (w + 3) / 4;
+  if ((long long)nb * th * tw * (c / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_input_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (c / 4)));
   RADNET_WINO4_LAUNCH(wino4_input_kernel, (long long)nb * th * tw * (c / 4), x, nb, h, w, c, th, tw, v);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_input");
   return RADNET_OK;
@@ -550,6 +563,7 @@ extern "C" int radnet_winograd4_output(radnet_ctx* ctx, const float* m, int32_t 
   if (!ctx || !m || !y) return RADNET_ERR_ARG;
   if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_output: n=%d, ldy=%d", n, ldy);
   const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
+  if ((long long)nb * th * tw * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_output_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (n / 4)));
   RADNET_WINO4_LAUNCH(wino4_output_kernel, (long long)nb * th * tw * (n / 4), m, nb, oh, ow, n, th, tw, scale, shift, act, y, ldy);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_output");
   return RADNET_OK;
@@ -560,6 +574,7 @@ extern "C" int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb,
   if (!ctx || !dy || !dz) return RADNET_ERR_ARG;
   if ((n & 3) || (ld_dy & 3) || ld_dy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_dy: n=%d, ld_dy=%d", n, ld_dy);
   const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
+  if ((long long)nb * th * tw * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_dy_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (n / 4)));
   RADNET_WINO4_LAUNCH(wino4_dy_kernel, (long long)nb * th * tw * (n / 4), dy, nb, oh, ow, n, ld_dy, th, tw, gscale, dz);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_dy");
   return RADNET_OK;
@@ -568,6 +583,7 @@ extern "C" int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb,
 extern "C" int radnet_winograd4_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate) {
   if (!ctx || !du || !dw) return RADNET_ERR_ARG;
   if ((n & 3) || (ldw & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_filter_grad: n=%d, ldw=%d must be multiples of 4", n, ldw);
+  if ((long long)c * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_filter_grad_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)c * (n / 4)));
   RADNET_WINO4_LAUNCH(wino4_filter_grad_kernel, (long long)c * (n / 4), du, c, n, ldw, dw, accumulate ? 1 : 0);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_filter_grad");
   return RADNET_OK;
