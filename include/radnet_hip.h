@@ -57,7 +57,9 @@ int radnet_tuned_shapes(radnet_ctx* ctx);
  * launches for the shapes in it: restarts skip the tuning step, and a profiler sees steady-state launches only. */
 int radnet_tune_save(radnet_ctx* ctx, const char* path);
 /* `ctx` uses (reads and extends) the table of `owner` from now on: the contexts an engine keeps for its concurrent lanes
- * (one per HIP stream) measure every shape once.  All calls on contexts that share a table come from one host thread. */
+ * (one per HIP stream) measure every shape once.  All calls on contexts that share a table come from one host thread.
+ * The read-only device tables the weight-gradient kernel keeps per conv geometry are shared the same way, so a context can
+ * meet a geometry for the first time inside a stream capture (its sibling built the table in an earlier eager run). */
 int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner);
 int radnet_tune_load(radnet_ctx* ctx, const char* path);
 /* Test hook: force every following conv GEMM launch to use output tile (tile_a x tile_b in {64,128}) and `slices` K

@@ -30,8 +30,6 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
     if (kv.second.d_units) (void)hipFree(kv.second.d_units);
     if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
   }
-  for (auto& kv : ctx->row_tables)
-    if (kv.second) (void)hipFree(kv.second);
   if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
   if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
   delete ctx;
@@ -57,9 +55,15 @@ extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
   return RADNET_OK;
 }
 
+radnet_ctx::RowTables::~RowTables() {
+  for (auto& kv : m)
+    if (kv.second) (void)hipFree(kv.second);
+}
+
 extern "C" int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner) {
   if (!ctx || !owner) return RADNET_ERR_ARG;
   ctx->tuned = owner->tuned;
+  ctx->row_tables = owner->row_tables;      // read-only device tables per conv geometry (tables this context built itself are freed here)
   return RADNET_OK;
 }
 

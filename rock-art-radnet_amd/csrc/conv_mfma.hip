@@ -1042,8 +1042,8 @@ radnet_unit_table* get_unit_table(radnet_ctx* ctx, int M, int N, int K, int bm, 
 // context (device memory, freed with it).
 const int* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
   const std::array<int, 11> key{d->nb, d->h, d->w_, d->c, d->oh, d->ow, d->stride, d->pad_t, d->pad_l, d->kh, d->kw};
-  auto it = ctx->row_tables.find(key);
-  if (it != ctx->row_tables.end()) return (const int*)it->second;
+  auto it = ctx->row_tables->m.find(key);
+  if (it != ctx->row_tables->m.end()) return (const int*)it->second;
   const int M = d->nb * d->oh * d->ow, mpad = radnet_cdiv(M, BK) * BK, taps = d->kh * d->kw;
   const int64_t bias = ((int64_t)d->pad_t * d->w_ + d->pad_l) * d->c * 4;
   std::vector<uint32_t> host((size_t)taps * mpad, 0x80000000u);
@@ -1062,7 +1062,7 @@ const int* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
   void* dev = nullptr;
   if (hipMalloc(&dev, host.size() * sizeof(uint32_t)) != hipSuccess) return nullptr;
   if (hipMemcpy(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  ctx->row_tables.emplace(key, dev);
+  ctx->row_tables->m.emplace(key, dev);
   return (const int*)dev;
 }
 

@@ -63,7 +63,14 @@ struct radnet_ctx {
   // measured launch choices; contexts of one engine share ONE table (radnet_share_tuning), calls come from one host thread
   std::shared_ptr<std::map<radnet_shape_key, radnet_tuned>> tuned = std::make_shared<std::map<radnet_shape_key, radnet_tuned>>();
   std::map<std::array<int, 6>, radnet_unit_table> unit_tables;
-  std::map<std::array<int, 11>, void*> row_tables;     // conv geometry -> device row table (conv_mfma.hip: get_row_table)
+  // conv geometry -> device row table (conv_mfma.hip: get_row_table): read-only once built, so the contexts of one engine share
+  // them like the tuning table (radnet_share_tuning) -- a context that first meets a geometry inside a graph capture must not
+  // have to build (allocate + copy) its table there.  Freed by the last context that holds the map.
+  struct RowTables {
+    std::map<std::array<int, 11>, void*> m;
+    ~RowTables();
+  };
+  std::shared_ptr<RowTables> row_tables = std::make_shared<RowTables>();
   hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
