@@ -97,6 +97,26 @@ def _time_us(fn, n=30, warm=5):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def winograd_executed_share(eng):
+    """Executed / algorithmic flops over the Winograd ops of every layer program the engine holds (forward, re-forward, weight
+    gradient): 2*positions*tiles*C*N against 2*M*N*9C."""
+    ex = al = 0.0
+    import collections
+    for key in list(eng._plans.keys()):
+        plan = collections.OrderedDict.__getitem__(eng._plans, key)       # (the cache's own lookup reorders it)
+        for name in ("ops", "fwd", "refwd", "bwd"):
+            for kind, p in (plan.get(name) or []) if isinstance(plan, dict) else []:
+                if kind in ("wino", "wino_reuse"):
+                    nb, hh, ww, c, n, T, form = p[1], p[2], p[3], p[4], p[5], p[9], p[15]
+                elif kind == "wino_wgrad":
+                    nb, hh, ww, c, n, T, form = p[1], p[2], p[3], p[4], p[5], p[10], p[13]
+                else:
+                    continue
+                ex += 2.0 * (form + 2) ** 2 * T * c * n
+                al += 2.0 * nb * hh * ww * n * 9 * c
+    return ex / al if al else 1.0
+
+
 def layers_3x3_table(eng, bp, rp):
     """north_star target "MFMA utilisation on ResNet50 stage-3/4 3x3 convs" (+ rpn_conv1), per layer class, each form alone on
     the chip, back-to-back launches between two HIP events on the launch stream: the Winograd form the step runs (F(4x4,3x3) or
@@ -351,8 +371,10 @@ def main():
         per = {}
         tot_ms = tot_fl = 0.0
         tot_n = 0
-        for cls, name in ((0, "conv_igemm_fwd"), (1, "conv_igemm_dgrad"), (2, "conv_wgrad")):
+        for cls, name in ((0, "conv_igemm_fwd"), (1, "conv_igemm_dgrad"), (2, "conv_wgrad"), (4, "conv_bwd_pair (dgrad + wgrad of a layer, one launch)")):
             ms, n, fl = eng.ctx.timing_read(cls)
+            if cls == 4 and not n:
+                continue
             per[name] = {"launches_per_step": n / args.roofline_steps / args.per_gpu_batch, "avg_us": 1e3 * ms / max(n, 1),
                          "tflops": fl / max(ms, 1e-9) / 1e9}
             tot_ms += ms; tot_fl += fl; tot_n += n
@@ -365,8 +387,9 @@ def main():
                                               "tflops": wfl / max(wms, 1e-9) / 1e9}
             tot_ms += wms; tot_fl += wfl
         ach = tot_fl / max(tot_ms, 1e-9) / 1e9
-        # executed flops: what the MFMAs really performed (Winograd layers execute 16*tiles*C*N*2 = 1/2.25 of their credit)
-        exec_fl = tot_fl - (wfl - wfl / 2.25 if wn else 0.0)
+        # executed flops: what the MFMAs really performed (a Winograd layer executes 2*positions*tiles*C*N: 1/4 of its credit as
+        # F(4x4,3x3) on whole tiles, 1/2.25 as F(2x2,3x3), a little more on maps that are not multiples of the tile)
+        exec_fl = tot_fl - (wfl * (1.0 - winograd_executed_share(eng)) if wn else 0.0)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
                 "schedule": "one lane, launches isolated (each GEMM launch alone on the chip between two HIP events); `value` is measured on the "

@@ -147,6 +147,12 @@ int radnet_winograd4_dy(radnet_ctx* ctx, const float* dy, int32_t nb, int32_t oh
 int radnet_winograd4_filter_grad(radnet_ctx* ctx, const float* du, int32_t c, int32_t n, int32_t ldw, float* dw, int32_t accumulate);
 int radnet_conv_dgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
 int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
+/* Weight gradient and data gradient of one layer from one descriptor (train.py's backward pass through a Conv2D: both read
+ * dy).  Issued as ONE launch whose workgroups alternate between the two problems when both run as 64x64-tile, 4-wave
+ * workgroups -- two short launches in a row each pay their own lockstep prologue / epilogue and launch gap, mixed they hide
+ * each other's -- and as radnet_conv_wgrad followed by radnet_conv_dgrad otherwise (other launch shapes, d->dx == 0,
+ * RADNET_NO_BWD_PAIR=1).  Same results as the two calls.  Timing class 4. */
+int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d);
 
 /* out[n] (+)= sum_m g[m][n] * gscale[n]   (bias gradients) */
 int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t n, int32_t ld, const float* gscale,
@@ -293,6 +299,7 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  * enqueues it on the context's stream.  No allocation, no synchronisation: running it on a capturing stream records it into
  * a hipGraph.  Argument slots per kind (i = integers, p = device pointers):
  *   CONV_FWD / CONV_DGRAD / CONV_WGRAD   conv
+ *   CONV_BWD     conv (radnet_conv_bwd: weight gradient + data gradient of the layer);  NOP: skipped
  *   MAXPOOL      p: x, y                     i: nb, h, w, c, k, s
  *   COLSUM       p: g, gscale|0, out         i: m, n, ld, accumulate
  *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy, form   (radnet_winograd_input + 16
@@ -306,7 +313,7 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
 enum {
   RADNET_OP_CONV_FWD = 1, RADNET_OP_CONV_DGRAD = 2, RADNET_OP_CONV_WGRAD = 3, RADNET_OP_MAXPOOL = 4, RADNET_OP_COLSUM = 5,
   RADNET_OP_WINO = 6, RADNET_OP_WINO_REUSE = 7, RADNET_OP_WINO_WGRAD = 8, RADNET_OP_SCATTER = 9, RADNET_OP_FILL0 = 10,
-  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12
+  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_NOP = 0
 };
 typedef struct radnet_op {
   int32_t kind;

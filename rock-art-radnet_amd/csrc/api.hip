@@ -178,7 +178,7 @@ extern "C" int radnet_timing_reset(radnet_ctx* ctx) {
 }
 
 extern "C" int radnet_timing_read(radnet_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops) {
-  if (!ctx || cls < 0 || cls > 3) return RADNET_ERR_ARG;
+  if (!ctx || cls < 0 || cls > 4) return RADNET_ERR_ARG;
   resolve_pending(ctx);
   if (ms) *ms = ctx->slots[cls].ms;
   if (launches) *launches = ctx->slots[cls].launches;

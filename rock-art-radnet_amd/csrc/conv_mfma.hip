@@ -252,8 +252,13 @@ __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB,
 //          second half of every 32-deep K tile (split-K INSIDE the workgroup: same LDS tile, half the staging work per
 //          thread, twice the waves per SIMD for the same number of workgroups -- a wave cannot hide its own staging
 //          instructions under its own MFMAs, another wave's can).  The halves are summed through LDS after the loop.
+// LDS floats of one workgroup of conv_igemm_body (two buffers of an A and a B tile)
+template <int BM, int BN, int BMODE>
+constexpr int igemm_lds_floats() { return 2 * (BM * kRowPitch + ((BMODE == 0) ? BK * (BN + 4) : BN * kRowPitch)); }
+
 template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __restrict__ lds, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
+                                                const unsigned grid_x) {
   constexpr int NT = 64 * WAVES;
   constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave in each direction
   constexpr int PB = BN + 4;                    // forward weights: k-major [BK][PB]
@@ -264,7 +269,6 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   // one LDS buffer: A row-major [BM][kRowPitch]; B k-major [BK][PB] (forward) or row-major [BN][kRowPitch] (dgrad)
   constexpr int kBufA = BM * kRowPitch;
   constexpr int kBufB = (BMODE == 0) ? BK * PB : BN * kRowPitch;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (kBufA + kBufB)];
   float* sA0 = lds;
   float* sB0 = lds + 2 * kBufA;
 
@@ -283,12 +287,12 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   // MFMA work whatever the tile count (stream-K style); a unit is (tile, k range, partial slot or -1).
   int m0, n0, unit_kb = 0, unit_ke = 0, slot = -1, slot0 = 0, n_slices = 1, tile_id = 0;
   if (g.units != nullptr) {
-    const int4 u0 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x];
-    const int4 u1 = reinterpret_cast<const int4*>(g.units)[2 * blockIdx.x + 1];
+    const int4 u0 = reinterpret_cast<const int4*>(g.units)[2 * bid_x];
+    const int4 u1 = reinterpret_cast<const int4*>(g.units)[2 * bid_x + 1];
     m0 = u0.x * BM; n0 = u0.y * BN; unit_kb = u0.z; unit_ke = u0.w;
     slot = u1.x; slot0 = u1.y; n_slices = u1.z; tile_id = u1.w;
   } else {
-    m0 = blockIdx.x * BM; n0 = blockIdx.y * BN;
+    m0 = bid_x * BM; n0 = bid_y * BN;
   }
 
   // ---- per-thread A rows: decode m -> (image, oh, ow) once
@@ -370,7 +374,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   }
 
   // batched launch (radnet_gemm_batched): problem blockIdx.z of a strided batch, same geometry
-  const long long bz = g.batch > 1 ? (long long)blockIdx.z : 0;
+  const long long bz = g.batch > 1 ? (long long)bid_z : 0;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(g.x + bz * g.x_bstride) - a_bias, g.x_bytes ? g.x_bytes + a_bias : 0u);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w + bz * g.w_bstride, g.w_bytes);
   const bool has_in_scale = g.in_scale != nullptr;
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     if (g.stamps != nullptr && tid == 0) {
-      unsigned long long* s = g.stamps + 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+      unsigned long long* s = g.stamps + 8ull * (bid_x + (unsigned long long)grid_x * bid_y);
       s[0] = t_start; s[1] = t_first; s[2] = t_loop; s[3] = t_end;
       s[4] = rt_start; s[5] = __builtin_amdgcn_s_memrealtime();
       s[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -728,6 +732,12 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
 #endif
 }
 
+template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<BM, BN, BMODE>()];
+  conv_igemm_body<BM, BN, BMODE, SMALLC, WAVES>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
 // ---- wgrad kernel -----------------------------------------------------------------------------------
 // dW[k][n] (+)= sum_m im2col(x)[m][k] * (dy[m][n] * gscale[n]).  Output tile BMK (k) x BN (n); the
 // reduction runs over output pixels m in steps of 32, optionally split across blockIdx.z (atomics).
@@ -751,12 +761,14 @@ struct WgradArgs {
 };
 
 template <int BMK, int BN>
-__global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
+constexpr int wgrad_lds_floats() { return 2 * BK * ((BMK + 4) + (BN + 4)); }
+
+template <int BMK, int BN>
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __restrict__ lds, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   constexpr int PA = BMK + 4, PB = BN + 4;
   constexpr int A_ITERS = BMK / 32, B_ITERS = BN / 32;
   constexpr int CPRA = BMK / 4, CPRB = BN / 4;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (PA + PB)];
   float* sA0 = lds;
   float* sB0 = lds + 2 * BK * PA;
 
@@ -764,7 +776,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const int k0 = blockIdx.x * BMK, n0 = blockIdx.y * BN;
+  const int k0 = bid_x * BMK, n0 = bid_y * BN;
 
   // this block's k range lies inside one kernel position when C % BMK == 0 (launcher guarantees)
   const int pos = k0 / g.C;
@@ -778,8 +790,8 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   if (g.gscale != nullptr && b_nv) gs = *reinterpret_cast<const float4*>(g.gscale + n0 + b_n4 * 4);
 
   const int nmt = (g.M + BK - 1) / BK;
-  const int zsplit = g.batch > 1 ? (int)(blockIdx.z % (unsigned)g.splits) : (int)blockIdx.z;
-  const long long bp = g.batch > 1 ? (long long)(blockIdx.z / (unsigned)g.splits) : 0;
+  const int zsplit = g.batch > 1 ? (int)(bid_z % (unsigned)g.splits) : (int)bid_z;
+  const long long bp = g.batch > 1 ? (long long)(bid_z / (unsigned)g.splits) : 0;
   const int mt_begin = zsplit * g.mt_per_split;
   int mt_end = mt_begin + g.mt_per_split;
   if (mt_end > nmt) mt_end = nmt;
@@ -790,7 +802,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   // bias gradient: the workgroups of the first k tile see every (dy * gscale) row of their m range exactly once on
   // its way into LDS; they keep a running column sum and add it to db at the end (keras Conv2D bias / the beta-free
   // FixedBatchNormalization shift: d/db = sum over pixels of the scaled output gradient)
-  const bool do_bias = g.db != nullptr && blockIdx.x == 0;
+  const bool do_bias = g.db != nullptr && bid_x == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // Row table (host-built once per conv geometry, get_row_table): rowtab[tap][m] = byte offset of input pixel
@@ -940,6 +952,45 @@ __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   }
 }
 
+template <int BMK, int BN>
+__global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[wgrad_lds_floats<BMK, BN>()];
+  conv_wgrad_body<BMK, BN>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- data gradient and weight gradient of one layer in ONE launch ---------------------------------------------------------
+// Both read the same dy and are independent of each other; as two launches on one stream they run one after the other, each
+// with its own lockstep prologue / epilogue phases and launch gap.  Here the workgroups of the two problems alternate in the
+// grid (even linear id: dgrad, odd: wgrad, the longer one fills the rest), so a CU holds workgroups of both and the phases of
+// one hide under the K loops of the other.  64x64 tiles, 4 waves, for both (what the tuner picks for the classifier's layers).
+struct PairMap {
+  unsigned n_a, n_w;            // workgroups of the dgrad / wgrad problem
+  unsigned ax, ay;              // dgrad grid (x, y); z = 1
+  unsigned wx, wy;              // wgrad grid (x, y); z = n_w / (wx * wy)
+};
+
+__global__ void __launch_bounds__(NTHREADS) conv_bwd_pair_kernel(GemmArgs ga, WgradArgs gw, PairMap pm) {
+  constexpr int kLds = igemm_lds_floats<64, 64, 1>() > wgrad_lds_floats<64, 64>() ? igemm_lds_floats<64, 64, 1>() : wgrad_lds_floats<64, 64>();
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  const unsigned b = blockIdx.x, both = 2u * (pm.n_a < pm.n_w ? pm.n_a : pm.n_w);
+  bool is_a;
+  unsigned idx;
+  if (b < both) {
+    is_a = (b & 1u) == 0u;
+    idx = b >> 1;
+  } else {
+    is_a = pm.n_a > pm.n_w;
+    idx = b - both + (both >> 1);
+  }
+  if (is_a) {
+    const unsigned by = idx / pm.ax;
+    conv_igemm_body<64, 64, 1, false, 4>(ga, lds, idx - by * pm.ax, by, 0u, pm.ax);
+  } else {
+    const unsigned plane = pm.wx * pm.wy, bz = idx / plane, r = idx - bz * plane, by = r / pm.wx;
+    conv_wgrad_body<64, 64>(gw, lds, r - by * pm.wx, by, bz);
+  }
+}
+
 // ---- launch helpers -----------------------------------------------------------------------------------
 constexpr int kNumCU = 256;
 
@@ -1084,6 +1135,23 @@ void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n
   else launch_igemm_w<BMODE, SMALLC, 4>(st, g, tc, grid);
 }
 
+// radnet_conv_bwd: the final launch of run_igemm (dgrad) / run_wgrad lands here instead of on the stream while
+// ctx->pair_capture is set; the measuring launches of a first, autotuned call are issued as usual (PairPause).
+struct PairCapture {
+  bool have_a = false, a_ok = false, have_w = false, w_ok = false;
+  GemmArgs ga;
+  unsigned ax = 0, ay = 0;
+  WgradArgs gw;
+  unsigned wx = 0, wy = 0, wz = 0;
+  double flops = 0.0;
+};
+struct PairPause {
+  radnet_ctx* ctx;
+  void* saved;
+  explicit PairPause(radnet_ctx* c) : ctx(c), saved(c->pair_capture) { c->pair_capture = nullptr; }
+  ~PairPause() { ctx->pair_capture = saved; }
+};
+
 int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   if (g.M >= (1 << 20) || g.OHOW >= (1 << 20)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: M=%d exceeds 2^20 rows", g.M);
@@ -1135,6 +1203,16 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       }
     }
     const int n_units = tb ? tb->n_units : 0;
+    if (ctx->pair_capture != nullptr) {
+      PairCapture* pc = (PairCapture*)ctx->pair_capture;
+      pc->have_a = true;
+      pc->a_ok = bmode == 1 && !smallc && t.bm == 64 && t.bn == 64 && t.waves != 8 && g.batch <= 1;
+      pc->ga = g;
+      pc->ax = g.units != nullptr ? (unsigned)n_units : (unsigned)radnet_cdiv(g.M, t.bm);
+      pc->ay = g.units != nullptr ? 1u : (unsigned)radnet_cdiv(g.N, t.bn);
+      pc->flops += 2.0 * g.M * g.N * g.K;
+      return RADNET_OK;
+    }
     if (bmode == 0) {
       if (smallc) launch_igemm<0, true>(ctx->stream, g, t, n_units);
       else launch_igemm<0, false>(ctx->stream, g, t, n_units);
@@ -1157,6 +1235,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     tc = TileChoice{nb->a, nb->b, nb->splits, nb->waves == 8 ? 8 : 4};
     (*ctx->tuned)[key] = *nb;
   } else if (ctx->autotune) {
+    PairPause pause(ctx);                       // trial launches are real launches
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int chunks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};      // K slices per tile
     std::vector<std::pair<float, TileChoice>> seen;
@@ -1306,6 +1385,15 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     if (splits > 1 && d->dw_accumulate == 0)  // atomics need a zeroed destination
       RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (batch > 1 ? (size_t)batch * dw_bs : (size_t)g.K * g.ldw) * sizeof(float), ctx->stream));
     dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits * (batch > 1 ? batch : 1)), block(NTHREADS);
+    if (ctx->pair_capture != nullptr) {
+      PairCapture* pc = (PairCapture*)ctx->pair_capture;
+      pc->have_w = true;
+      pc->w_ok = bmk == 64 && bn == 64 && batch <= 1;
+      pc->gw = g;
+      pc->wx = grid.x; pc->wy = grid.y; pc->wz = grid.z;
+      pc->flops += 2.0 * g.M * g.N * g.K;
+      return RADNET_OK;
+    }
     if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
     else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
     else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
@@ -1326,6 +1414,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     bmk = nb->a; bn = nb->b; splits = nb->splits;
     (*ctx->tuned)[key] = *nb;
   } else if (ctx->autotune && d->dw_accumulate != 1) {
+    PairPause pause(ctx);                       // trial launches are real launches
     struct WCand { float ms; int bmk, bn, s; };
     std::vector<WCand> seen;
     for (int cb = 128; cb >= 64; cb -= 64) {
@@ -1386,6 +1475,37 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
 }
 
 extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) { return run_wgrad(ctx, d, 1, 0, 0, 0); }
+
+// Weight gradient and data gradient of one layer (the same descriptor: both read dy) as ONE launch when both problems run as
+// 64x64-tile, 4-wave workgroups (conv_bwd_pair_kernel); otherwise -- other tile choices, or RADNET_NO_BWD_PAIR=1 -- the two
+// launches in the order wgrad, dgrad.  Results are those of the separate launches (same kernels' code, same launch shapes).
+extern "C" int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  if (!ctx || !d) return RADNET_ERR_ARG;
+  static const bool disabled = getenv("RADNET_NO_BWD_PAIR") != nullptr;
+  if (disabled || ctx->pair_capture != nullptr || !d->dx) {
+    int rc = radnet_conv_wgrad(ctx, d);
+    return rc != RADNET_OK || !d->dx ? rc : radnet_conv_dgrad(ctx, d);
+  }
+  PairCapture pc;
+  const int timed = ctx->timing;
+  ctx->timing = 0;
+  ctx->pair_capture = &pc;
+  int rc = radnet_conv_wgrad(ctx, d);           // host-side preparation (tables, memsets of overwrite mode) happens here
+  if (rc == RADNET_OK) rc = radnet_conv_dgrad(ctx, d);
+  ctx->pair_capture = nullptr;
+  ctx->timing = timed;
+  if (rc != RADNET_OK) return rc;
+  if (!(pc.have_a && pc.have_w && pc.a_ok && pc.w_ok)) {      // not the fusable shapes: issue them one after the other
+    rc = radnet_conv_wgrad(ctx, d);
+    return rc != RADNET_OK ? rc : radnet_conv_dgrad(ctx, d);
+  }
+  PairMap pm{pc.ax * pc.ay, pc.wx * pc.wy * pc.wz, pc.ax, pc.ay, pc.wx, pc.wy};
+  radnet_timing_begin(ctx);
+  hipLaunchKernelGGL(conv_bwd_pair_kernel, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, pc.ga, pc.gw, pm);
+  RADNET_CHECK_LAUNCH(ctx, "conv_bwd_pair");
+  radnet_timing_end(ctx, 4, pc.flops);
+  return RADNET_OK;
+}
 
 extern "C" int radnet_wgrad_batched(radnet_ctx* ctx, const float* a, const float* dy, float* dw, int32_t batch, int32_t m, int32_t k, int32_t n,
                                     int32_t accumulate) {

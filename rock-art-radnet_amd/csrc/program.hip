@@ -80,6 +80,8 @@ extern "C" int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t
       case RADNET_OP_CONV_FWD: rc = radnet_conv_fwd(ctx, &o.conv); break;
       case RADNET_OP_CONV_DGRAD: rc = radnet_conv_dgrad(ctx, &o.conv); break;
       case RADNET_OP_CONV_WGRAD: rc = radnet_conv_wgrad(ctx, &o.conv); break;
+      case RADNET_OP_CONV_BWD: rc = radnet_conv_bwd(ctx, &o.conv); break;
+      case RADNET_OP_NOP: rc = RADNET_OK; break;
       case RADNET_OP_MAXPOOL:
         rc = radnet_maxpool_fwd(ctx, (const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5]);
         break;

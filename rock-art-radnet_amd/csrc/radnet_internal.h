@@ -80,7 +80,8 @@ struct radnet_ctx {
   // timing of GEMM-class launches with HIP events on `stream` (bench roofline leg)
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  radnet_timing_slot slots[4];      // 0 fwd, 1 dgrad, 2 wgrad, 3 Winograd layers of a program
+  radnet_timing_slot slots[5];      // 0 fwd, 1 dgrad, 2 wgrad, 3 Winograd layers of a program, 4 dgrad + wgrad of a layer in one launch
+  void* pair_capture = nullptr;     // conv_mfma.hip: radnet_conv_bwd collects the two launches of a layer here instead of issuing them
   // pending (not yet resolved) event pairs are resolved lazily to avoid a sync per launch
   static constexpr int kMaxPending = 4096;
   hipEvent_t pend0[kMaxPending];

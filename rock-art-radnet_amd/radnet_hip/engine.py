@@ -567,11 +567,20 @@ class FasterRCNNEngine:
             return ent[0]
         arr = (L.Op * max(len(ops), 1))()
         ptr = lambda v: v.data_ptr() if hasattr(v, "data_ptr") else v
+        paired = False
         for k, (kind, p) in enumerate(ops):
             o = arr[k]
+            if paired:                              # the dgrad half of a pair: issued by the entry before (stays a no-op slot)
+                paired = False
+                o.kind = L.OP_NOP
+                continue
             if kind in ("conv", "dgrad", "wgrad"):
                 o.kind = {"conv": L.OP_CONV_FWD, "dgrad": L.OP_CONV_DGRAD, "wgrad": L.OP_CONV_WGRAD}[kind]
                 o.conv = p
+                # weight gradient and data gradient of one layer (same descriptor) -> one launch (radnet_conv_bwd)
+                if kind == "wgrad" and k + 1 < len(ops) and ops[k + 1][0] == "dgrad" and ops[k + 1][1] is p:
+                    o.kind = L.OP_CONV_BWD
+                    paired = True
             elif kind == "maxpool":
                 x, y, nb, hh, ww, c, kk, st = p
                 o.kind = L.OP_MAXPOOL

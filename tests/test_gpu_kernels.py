@@ -192,6 +192,54 @@ def test_conv_dgrad_wgrad(ctx, case):
     close(db2.cpu().numpy(), 2 * db_ref)
 
 
+@pytest.mark.parametrize("case", [(3, 7, 7, 512, 512, 3, 1), (3, 7, 7, 2048, 512, 1, 0), (1, 19, 23, 128, 192, 3, 1), (2, 9, 11, 64, 96, 1, 0)])
+@pytest.mark.parametrize("shape", [(64, 64, 1), (64, 64, 3), (64, 64, -2), (128, 64, 1), None])
+def test_conv_bwd_one_launch_equals_the_two_launches(ctx, case, shape):
+    """radnet_conv_bwd (weight gradient + data gradient of a layer from one descriptor): with 64x64 tiles -- un-split, K-split
+    with the in-launch reduction, XCD-ordered -- the two problems share ONE launch (conv_bwd_pair_kernel); with other shapes
+    (128x64) and with the heuristic choice (None) it issues the two launches.  Either way: dx (+ residual add, ReLU mask), dw,
+    db against the oracle, and accumulate mode adds on top."""
+    from radnet_hip import lib as L
+    from oracle import dense
+    nb, h, w, cin, cout, k, pad = case
+    rs = np.random.RandomState(sum(case) + 3)
+    x = np.maximum(rs.standard_normal((nb, h, w, cin)), 0).astype(np.float32)
+    wt = (rs.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    dy = rs.standard_normal((nb, h, w, cout)).astype(np.float32)
+    gs = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    add = rs.standard_normal((nb, h, w, cin)).astype(np.float32)
+    dx_ref, dw_ref, db_ref = dense.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), (dy * gs).astype(np.float64), 1, (pad,) * 4)
+    dx_ref = (dx_ref + add) * (x > 0)
+    xd, wd, dyd, gsd, addd = dev(x), dev(wt.reshape(-1, cout)), dev(dy), dev(gs), dev(add)
+    dx = torch.full((nb, h, w, cin), float("nan"), device="cuda")
+    dw = torch.full((k * k * cin, cout), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    d = conv_desc(L, xd, wd, dx, nb, h, w, cin, h, w, k, 1, pad, cout, cout)
+    d.dy, d.ld_dy, d.gscale = dyd.data_ptr(), cout, gsd.data_ptr()
+    d.dx, d.ld_dx, d.dx_add, d.ld_dx_add, d.dx_mask, d.ld_dx_mask = dx.data_ptr(), cin, addd.data_ptr(), cin, xd.data_ptr(), cin
+    d.dw, d.dw_accumulate, d.db = dw.data_ptr(), 0, db.data_ptr()
+    if shape is not None:
+        nk = k * k * cout // 32                                   # K tiles of the dgrad problem
+        if (abs(shape[2]) > 1 and nk // abs(shape[2]) < 1) or cin % shape[0]:
+            pytest.skip("fewer K tiles than slices / weight-gradient tile does not divide the channels")
+        ctx.check(ctx.lib.radnet_force_config(ctx.h, *shape), "force")
+    try:
+        ctx.check(ctx.lib.radnet_conv_bwd(ctx.h, C.byref(d)), "conv_bwd")
+        ctx.sync()
+        close(dx.cpu().numpy(), dx_ref)
+        close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
+        close(db.cpu().numpy(), db_ref)
+        d.dw_accumulate = 1
+        dx.fill_(float("nan"))
+        ctx.check(ctx.lib.radnet_conv_bwd(ctx.h, C.byref(d)), "conv_bwd")
+        ctx.sync()
+        close(dx.cpu().numpy(), dx_ref)
+        close(dw.cpu().numpy(), 2 * dw_ref.reshape(-1, cout))
+        close(db.cpu().numpy(), 2 * db_ref)
+    finally:
+        ctx.check(ctx.lib.radnet_force_config(ctx.h, 0, 0, 0), "force off")
+
+
 def test_wgrad_strided_1x1(ctx):
     from radnet_hip import lib as L
     from oracle import dense
