@@ -35,6 +35,16 @@ SHAPES = [
     ("rpn_conv1 3x3 1024->512 128x128 x2", 1, 38, 63, 1024, 512, 3, 1, 1, False, (128, 128, 4)),
 ]
 
+if os.environ.get("RADNET_PROBE_SET") == "head":          # the classifier's layers: 20 RoIs x 7x7 = 980 rows
+    SHAPES = [
+        ("res5x_2b  3x3 512->512 (s=-2)", 20, 7, 7, 512, 512, 3, 1, 1, False, (64, 64, -2)),
+        ("res5x_2b  3x3 512->512 (s=-6)", 20, 7, 7, 512, 512, 3, 1, 1, False, (64, 64, -6)),
+        ("res5x_2b  3x3 512->512 (s=4)", 20, 7, 7, 512, 512, 3, 1, 1, False, (64, 64, 4)),
+        ("res5x_2c  1x1 512->2048 +res", 20, 7, 7, 512, 2048, 1, 1, 0, True, (64, 64, 1)),
+        ("res5x_2a  1x1 2048->512 (s=2)", 20, 7, 7, 2048, 512, 1, 1, 0, False, (64, 64, 2)),
+        ("res5x_2a  1x1 2048->512 (s=4)", 20, 7, 7, 2048, 512, 1, 1, 0, False, (64, 64, 4)),
+        ("res5a_1   1x1 1024->2048", 20, 7, 7, 1024, 2048, 1, 1, 0, False, (64, 128, -1)),
+    ]
 
 WAVES = int(os.environ.get("RADNET_PROBE_WAVES", "4"))      # waves per workgroup of the probed launches (4 or 8)
 
