@@ -97,6 +97,25 @@ def _time_us(fn, n=30, warm=5):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def committed_pmc_traffic():
+    """HBM bytes per launch of the dominant GEMM kernel from the committed PMC passes of this same command
+    (profiles/r02_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
+    tools/collect_profiles.sh, FETCH_SIZE doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  A profiler
+    cannot run inside this process: the figure is the last committed measurement, or None when the file is not there."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.txt")
+    try:
+        for line in open(path):
+            m = re.search(r"^\s*(conv_igemm_kernel<64, 64, 0, false, 4>)\s+per launch: FETCH_SIZE\s+([0-9.]+) MB \(x2 =\s+([0-9.]+) MB\)\s+WRITE_SIZE\s+([0-9.]+) MB", line)
+            if m:
+                return {"kernel": m.group(1), "bytes": (float(m.group(3)) + float(m.group(4))) * 1e6,
+                        "fetch_bytes_corrected": float(m.group(3)) * 1e6, "write_bytes": float(m.group(4)) * 1e6,
+                        "source": "profiles/r02_pmc_summary.txt (separate --pmc passes of this command; not measured in this run)"}
+    except OSError:
+        pass
+    return None
+
+
 def winograd_executed_share(eng):
     """Executed / algorithmic flops over the Winograd ops of every layer program the engine holds (forward, re-forward, weight
     gradient): 2*positions*tiles*C*N against 2*M*N*9C."""
@@ -391,7 +410,7 @@ def main():
         # F(4x4,3x3) on whole tiles, 1/2.25 as F(2x2,3x3), a little more on maps that are not multiples of the tile)
         exec_fl = tot_fl - (wfl * (1.0 - winograd_executed_share(eng)) if wn else 0.0)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
+                "traffic": (committed_pmc_traffic() or {}).get("bytes"), "traffic_detail": committed_pmc_traffic(), "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
                 "schedule": "one lane, launches isolated (each GEMM launch alone on the chip between two HIP events); `value` is measured on the "
                             "pipelined schedule, where lanes overlap -- gemm_ms_per_image here may exceed ms_per_step",
                 "winograd_credit": "Winograd layers are timed per layer (3 kernels) and credited the algorithmic 2*M*N*9C flops, not the 4x (F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer they execute",
