@@ -287,6 +287,12 @@ class FasterRCNNEngine:
         self.dense_w, self.dense_b = self.head_arena.param("dense/kernel"), self.head_arena.param("dense/bias")
         self.dense_dw, self.dense_db = self.head_arena.grad("dense/kernel"), self.head_arena.grad("dense/bias")
 
+    def sync_inference_filters(self):
+        """Winograd filter transforms of the classifier's 3x3 convs (inference plans only) after the head weights changed."""
+        if getattr(self, "_inference_filters_stale", False):
+            self._inference_filters_stale = False
+            self._refresh_winograd([n for n in self.INFERENCE_WINOGRAD_LAYERS if getattr(self.convs.get(n), "wino_u", None) is not None])
+
     def refresh_head_shift(self):
         """shift = scale * bias + t0 for every stage-5 conv (FixedBatchNormalization.py:59-85 folded)."""
         bias = self.head_arena.p[self.head_bias_off:self.head_bias_off + self.head_bias_len]
@@ -385,8 +391,15 @@ class FasterRCNNEngine:
     if os.environ.get("RADNET_WINOGRAD_EXTRA"):        # experiment knob: comma-separated layer names
         WINOGRAD_LAYERS = WINOGRAD_LAYERS + tuple(os.environ["RADNET_WINOGRAD_EXTRA"].split(","))
 
-    def _uses_winograd(self, c):
-        return self.use_winograd and c.name in self.WINOGRAD_LAYERS and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
+    # Inference-only Winograd layers: the classifier's 3x3 convs on ALL RoIs of a tile (RADNet's predict path: 300 RoIs,
+    # M = 14 700).  Their weights train, so in the train step a filter transform per update would eat the gain at M = 980;
+    # at inference the transform is made once per weight change (sync_inference_filters).
+    INFERENCE_WINOGRAD_LAYERS = tuple("res5%s_branch2b" % b for b in "abc")
+
+    def _uses_winograd(self, c, inference=False):
+        listed = c.name in self.WINOGRAD_LAYERS or (inference and c.name in self.INFERENCE_WINOGRAD_LAYERS
+                                                    and os.environ.get("RADNET_NO_INFERENCE_WINOGRAD", "0") != "1")
+        return self.use_winograd and listed and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
 
     # F(4x4,3x3) (36 GEMMs on a quarter of the tiles) where it measured faster than F(2x2,3x3) at 1000x600
     # (tools/winograd_timing.py; bench.py roofline.layers_3x3): RADNET_WINOGRAD_TILE=2 / 4 forces one form everywhere.
@@ -400,19 +413,20 @@ class FasterRCNNEngine:
 
     def _refresh_winograd(self, names=None):
         """Filter transform U = G g G^T of the Winograd layers (all of them, or the named ones after a weight update)."""
-        for name in (names if names is not None else self.WINOGRAD_LAYERS):
+        for name in (names if names is not None else self.WINOGRAD_LAYERS + tuple(n for n in self.INFERENCE_WINOGRAD_LAYERS
+                                                                                   if getattr(self.convs.get(n), "wino_u", None) is not None)):
             c = self.convs.get(name)
-            if c is None or not self._uses_winograd(c):
+            if c is None or not self._uses_winograd(c, inference=True):
                 continue
             if c.wino_u is None:
-                c.wino_m = self._wino_form(c)
+                c.wino_m = 4 if name in self.INFERENCE_WINOGRAD_LAYERS else self._wino_form(c)
                 c.wino_u = torch.empty((c.wino_m + 2) ** 2, c.cin, c.cout, dtype=torch.float32, device=self.dev)
             self.ctx.call("radnet_winograd4_filter" if c.wino_m == 4 else "radnet_winograd_filter", c.weight, c.cin, c.cout, c.ldw, c.wino_u)
 
-    def _fwd_op(self, c, x, nb, h, w, y, keep, relu=True):
+    def _fwd_op(self, c, x, nb, h, w, y, keep, relu=True, inference=False):
         """Forward op of conv `c` on x -> y: the direct implicit GEMM, or the Winograd form for the layers listed above."""
         d, oh, ow = self._desc(c, x, nb, h, w, y, relu=relu)
-        if not self._uses_winograd(c):
+        if not self._uses_winograd(c, inference):
             return ("conv", d), d
         if c.wino_u is None:
             self._refresh_winograd([c.name])
@@ -834,6 +848,8 @@ class FasterRCNNEngine:
                       C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0)
         if arena is self.rpn_arena:
             self._refresh_winograd(["rpn_conv1"])          # its forward runs on the transformed filter
+        elif arena is getattr(self, "head_arena", None):
+            self._inference_filters_stale = True           # transformed lazily, by the next inference pass (if any)
 
     def zero_grads(self, arena):
         self.ctx.call("radnet_fill_zero", arena.g, C.c_uint64(arena.n * 4))
@@ -877,7 +893,9 @@ class FasterRCNNEngine:
             ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
             oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
             a = buf(R, oh, ow, f1); da, _, _ = self._desc(ca, cur, R, h, w, a); fwd.append(("conv", da))
-            bb = buf(R, oh, ow, f2); db, _, _ = self._desc(cb, a, R, oh, ow, bb); fwd.append(("conv", db))
+            bb = buf(R, oh, ow, f2)
+            op_b, db = self._fwd_op(cb, a, R, oh, ow, bb, keep, relu=True, inference=not training)
+            fwd.append(op_b)
             ds = None
             if first:
                 sc = buf(R, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, R, h, w, sc, relu=False); fwd.append(("conv", ds))
@@ -984,6 +1002,8 @@ class FasterRCNNEngine:
         gradient w.r.t. the logits are computed in the same launch as the dense heads (csrc/head_tail.hip); head_backward
         then skips its loss pass.  group_live: per group 0/1 -- 0 = that image takes no classifier step (zero gradient rows)."""
         G = hp.get("groups", 1)
+        if "live" not in hp:
+            self.sync_inference_filters()
         if G == 1:
             self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
         else:

@@ -29,6 +29,8 @@ def rpn_forward(eng, bplan):
 
 
 def _head_desc(eng, hp):
+    if "live" not in hp and hasattr(eng, "sync_inference_filters"):
+        eng.sync_inference_filters()            # inference plans run the classifier's 3x3 convs on transformed filters
     h = L.HeadDesc()
     h.fmap, h.fh, h.fw, h.fc = hp["F"].data_ptr(), hp["fh"], hp["fw"], 1024
     h.rois, h.n_rois, h.pool, h.pooled = hp["rois"].data_ptr(), hp["R"], 14, hp["pooled"].data_ptr()

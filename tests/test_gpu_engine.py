@@ -448,3 +448,41 @@ def test_default_config_augmentations_train_on_changing_tile_sizes():
     assert len(set(sizes)) >= 2, sizes                 # (the resize to img_size on the short side absorbs pure rotations)
     new = [i for i in range(16) if sizes[i] not in sizes[:i]]
     assert min(took[i] for i in new[1:]) < 0.5 * took[0], (new, took)
+
+
+def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
+    """Inference head plans (DetectorModel.predict / RADNet's tile path) run the classifier's 3x3 convs as Winograd F(4x4,3x3)
+    on filters transformed once per weight change; training plans keep the direct form.  Same inputs through both: equal within
+    the stated tolerance, against the oracle too; after an Adam step on the head arena the inference pass sees the new weights."""
+    from oracle import dense
+    C, P, eng = setup
+    rs = np.random.RandomState(17)
+    F = np.maximum(rs.standard_normal((1, 20, 31, 1024)), 0).astype(np.float32) * 3
+    R = 40
+    rois = np.stack([rs.randint(0, 25, R), rs.randint(0, 14, R), rs.randint(1, 12, R), rs.randint(1, 10, R)], 1).astype(np.float32)
+    Fd = torch.from_numpy(F).cuda()
+    hi = eng._plan_head(R, 20, 31, Fd, training=False)
+    assert [k for k, _ in hi["fwd"]].count("wino") == 3
+    ht = eng._plan_head(R, 20, 31, Fd, training=True)
+    assert [k for k, _ in ht["fwd"]].count("wino") == 0
+    for hp in (hi, ht):
+        hp["rois"].copy_(torch.from_numpy(rois))
+        eng.head_forward(hp)
+    pc, pr, _ = dense.head_forward(P, F, rois, 7)
+    for hp in (hi, ht):
+        assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 1e-3 and rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 1e-3
+    assert rel_err(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy()) < 2e-4
+    before = hi["pregr"].cpu().numpy().copy()
+    try:
+        eng.head_arena.g.normal_(0, 1e-2)                                   # any gradient: the weights move by ~lr each
+        for _ in range(20):
+            eng.adam(eng.head_arena, zero_grad=False)
+        eng.refresh_head_shift()
+        for hp in (hi, ht):
+            eng.head_forward(hp)
+        moved = rel_err(hi["pregr"].cpu().numpy(), before)
+        assert moved > 1e-3, moved                                          # the update is visible ...
+        assert rel_err(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy()) < 2e-4      # ... and both forms agree on it
+    finally:
+        eng.set_weights(P)                                                  # module-scoped engine: restore
+        eng.head_arena.g.zero_()
