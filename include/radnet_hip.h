@@ -273,6 +273,12 @@ int64_t radnet_host_choice_round(double* live_p, int64_t* live_idx, int64_t* n_l
 /* uint8 BGR HWC image -> fp32 NHWC with `cpad` channels (zeros beyond 3), minus the caffe BGR means
  * (RADNet.py:83-87 / utils.py:468-472 with keras 'caffe' preprocess_input). */
 int radnet_preprocess_bgr(radnet_ctx* ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cpad, float* out);
+/* dst[0..bytes) = src[0..bytes) by a kernel on the context's stream; either side may be pinned host memory (hipHostMalloc /
+ * torch pin_memory: mapped into the device's address space).  The step's small transfers between host and device (image panel
+ * in, anchor label maps out and back, RoI class codes out: utils.py:777-813, train.py:300-330 run on the host in the reference)
+ * go through this instead of hipMemcpyAsync: an asynchronous copy enqueued on a stream with a few layer programs in arrears
+ * was measured to block the enqueuing host thread for 7-11 ms (tools/fill_drain_probe.py); a kernel launch never did. */
+int radnet_copy_bytes(radnet_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 /* cv2.resize(img, (dw, dh), interpolation=INTER_CUBIC) for uint8 HWC images (RADNet.py:72, utils.py:442-446):
  * a = -0.75 bicubic, half-pixel centres, replicated borders, OpenCV's 11-bit fixed-point arithmetic.
  * Parity unpinned (OpenCV absent offline). */

@@ -580,6 +580,28 @@ extern "C" int radnet_preprocess_bgr(radnet_ctx* ctx, const uint8_t* img, int32_
   return RADNET_OK;
 }
 
+namespace {
+// 16-byte lanes, then the tail byte by byte.  Either side may be pinned host memory (mapped into the device's address space).
+__global__ void __launch_bounds__(256) copy_bytes_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, unsigned long long n16,
+                                                         unsigned long long bytes) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (unsigned long long i = n16 * 16 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int radnet_copy_bytes(radnet_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return RADNET_ERR_ARG;
+  if (!bytes) return RADNET_OK;
+  const bool aligned = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  const unsigned long long n16 = aligned ? bytes / 16 : 0;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid_for((long long)(n16 ? n16 : bytes), 256, 2048)), dim3(256), 0, ctx->stream, (uint8_t*)dst, (const uint8_t*)src,
+                     n16, (unsigned long long)bytes);
+  RADNET_CHECK_LAUNCH(ctx, "copy_bytes");
+  return RADNET_OK;
+}
+
 extern "C" int radnet_fill_zero(radnet_ctx* ctx, void* p, uint64_t bytes) {
   if (!ctx || !p) return RADNET_ERR_ARG;
   RADNET_CHECK_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));

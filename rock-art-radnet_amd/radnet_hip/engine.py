@@ -683,6 +683,20 @@ class FasterRCNNEngine:
                 p[6] = 1 if (flag or prezeroed) else 0
 
     # ------------------------------------------------------------------------------------------ forward pieces
+    KERNEL_COPIES = os.environ.get("RADNET_KERNEL_COPIES", "1") == "1"
+
+    def _copy(self, dst, src):
+        """dst <- src (same byte count, contiguous; one side pinned host memory) on the current lane.  A copy kernel reading /
+        writing the mapped host buffer instead of hipMemcpyAsync: the latter was measured to block the enqueuing host thread
+        for 7-11 ms when the lane has a few layer programs in arrears (radnet_copy_bytes, include/radnet_hip.h)."""
+        if not self.KERNEL_COPIES:
+            dst.copy_(src, non_blocking=True)
+            return
+        n = dst.numel() * dst.element_size()
+        if n != src.numel() * src.element_size() or not dst.is_contiguous() or not src.is_contiguous():
+            raise L.RadnetError("engine._copy: %d != %d bytes, or a strided side" % (n, src.numel() * src.element_size()))
+        self.ctx.call("radnet_copy_bytes", dst, src, C.c_uint64(n))
+
     def upload_image(self, img_bgr_u8, slot=0):
         """uint8 BGR HWC host image -> preprocessed fp32 NHWC(4) on device (RADNet.py:83-87)."""
         H, W = img_bgr_u8.shape[:2]
@@ -711,7 +725,7 @@ class FasterRCNNEngine:
                 plan["raw_free"].record()
             torch.cuda.current_stream().wait_event(plan["raw_free"])
         else:
-            plan["raw"].copy_(src, non_blocking=True)
+            self._copy(plan["raw"], src)
             plan["raw_free"].record()
         self.ctx.call("radnet_preprocess_bgr", plan["raw"], H, W, 4, plan["x"])
         plan["raw_read"].record()
@@ -735,7 +749,7 @@ class FasterRCNNEngine:
             if img.shape[:2] != (H, W):
                 raise L.RadnetError("upload_images: images of one mini-batch must share their size")
             np.copyto(plan["h_raws"][i].numpy(), img)
-            plan["raws"][i].copy_(plan["h_raws"][i], non_blocking=True)
+            self._copy(plan["raws"][i], plan["h_raws"][i])
         plan["raw_free"].record()
         for i in range(nb):
             self.ctx.call("radnet_preprocess_bgr", plan["raws"][i], H, W, 4, plan["x"][i])
@@ -1095,8 +1109,8 @@ class FasterRCNNEngine:
                                             float(self.C.rpn_max_overlap), P["valid"].data_ptr(), P["overlap"].data_ptr(), P["regr"].data_ptr(),
                                             P["best"].data_ptr(), P["nfor"].data_ptr(), P["scratch"].data_ptr())
         self.ctx.check(rc, "radnet_anchor_targets")
-        P["h_valid"].copy_(P["valid"], non_blocking=True)
-        P["h_overlap"].copy_(P["overlap"], non_blocking=True)
+        self._copy(P["h_valid"], P["valid"])
+        self._copy(P["h_overlap"], P["overlap"])
         P["event"].record()
         P["g"] = g
         return P
@@ -1107,7 +1121,7 @@ class FasterRCNNEngine:
         P["event"].synchronize()
         valid = P["h_valid"].numpy()
         n_pos = subsample_valid(valid, P["h_overlap"].numpy())
-        P["valid"].copy_(P["h_valid"], non_blocking=True)
+        self._copy(P["valid"], P["h_valid"])
         self.ctx.call("radnet_anchor_targets_pack", P["valid"], P["overlap"], P["regr"], P["fw"], P["fh"], self.A, C.c_double(float(self.C.std_scaling)),
                       P["ycls"], P["yregr"])
         return P["ycls"], P["yregr"], n_pos
@@ -1143,8 +1157,8 @@ class FasterRCNNEngine:
                                          self.regr_std.ctypes.data_as(C.POINTER(C.c_double)), int(self.bg), P["keep"].data_ptr(), P["cls"].data_ptr(),
                                          P["box"].data_ptr(), P["t"].data_ptr(), P["iou"].data_ptr(), n_dev.data_ptr())
         self.ctx.check(rc, "radnet_roi_targets")
-        P["h_cls"][:n_max].copy_(P["cls"][:n_max], non_blocking=True)
-        P["h_n"].copy_(n_dev, non_blocking=True)
+        self._copy(P["h_cls"][:n_max], P["cls"][:n_max])
+        self._copy(P["h_n"], n_dev)
         if "event" not in P:
             P["event"] = torch.cuda.Event()
         P["event"].record()
@@ -1162,7 +1176,7 @@ class FasterRCNNEngine:
         k = len(sel)
         o = group * (hp["R"] // hp.get("groups", 1))
         P["h_sel"][:k] = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32))
-        P["sel"][:k].copy_(P["h_sel"][:k], non_blocking=True)
+        self._copy(P["sel"][:k], P["h_sel"][:k])
         self.ctx.call("radnet_roi_batch_pack", P["sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"][o:], hp["y1"][o:], hp["y2"][o:])
 
     def idle_roi_group(self, hp, group):

@@ -195,6 +195,7 @@ def load_library():
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_resize_bicubic_u8": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),
+        "radnet_copy_bytes": (C.c_int, [vp, vp, vp, C.c_uint64]),
         "radnet_program_run": (C.c_int, [vp, C.POINTER(Op), i32]),
         "radnet_rpn_forward": (C.c_int, [vp, C.POINTER(Op), i32, C.POINTER(Op), i32]),
         "radnet_predict_tile": (C.c_int, [vp, C.POINTER(TileDesc)]),
