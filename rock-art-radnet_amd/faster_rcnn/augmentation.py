@@ -73,16 +73,19 @@ def warp_affine_u8(src, mat, dsize):
     sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
     fx, fy = X & 31, Y & 31
     sh, sw = src.shape[:2]
-    src3 = src.reshape(sh, sw, -1).astype(np.int64)
-
-    def tap(yy, xx):
-        inside = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
-        v = src3[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)]
-        return v * inside[..., None]
-
-    acc = (tap(sy, sx) * (32 * (32 - fx) * (32 - fy))[..., None] + tap(sy, sx + 1) * (32 * fx * (32 - fy))[..., None]
-           + tap(sy + 1, sx) * (32 * (32 - fx) * fy)[..., None] + tap(sy + 1, sx + 1) * (32 * fx * fy)[..., None])
-    out = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+    ch = src.size // (sh * sw)
+    # source with a one-pixel border of zeros: a tap outside the image (clamped to the border) reads the constant 0
+    padded = np.zeros((sh + 2, sw + 2, ch), dtype=np.int32)
+    padded[1:-1, 1:-1] = src.reshape(sh, sw, ch)
+    flat = padded.reshape(-1, ch)
+    y0, y1 = np.clip(sy, -1, sh) + 1, np.clip(sy + 1, -1, sh) + 1
+    x0, x1 = np.clip(sx, -1, sw) + 1, np.clip(sx + 1, -1, sw) + 1
+    pitch = sw + 2
+    fx32, fy32 = fx.astype(np.int32), fy.astype(np.int32)
+    w00, w01 = (32 * (32 - fx32) * (32 - fy32))[..., None], (32 * fx32 * (32 - fy32))[..., None]
+    w10, w11 = (32 * (32 - fx32) * fy32)[..., None], (32 * fx32 * fy32)[..., None]
+    acc = flat[y0 * pitch + x0] * w00 + flat[y0 * pitch + x1] * w01 + flat[y1 * pitch + x0] * w10 + flat[y1 * pitch + x1] * w11
+    out = ((acc + (1 << 14)) >> 15).astype(np.uint8)                  # weights sum to 2^15: the result stays in 0..255
     return out.reshape((dh, dw) + src.shape[2:])
 
 
