@@ -721,3 +721,22 @@ def test_select_nms_kernel_matches_reference_and_full_sort(ctx, case):
     if kind in ("distinct", "tiny") and len(np.unique(cls)) == n:
         ref = glue.rpn_to_roi(pred[:, :A].reshape(1, rows, cols, A), pred[:, A:5 * A].reshape(1, rows, cols, 4 * A), Cc, True, mb, thr)
         assert np.array_equal(R_new, ref)
+
+
+def test_copy_bytes_between_pinned_host_and_device(ctx):
+    """radnet_copy_bytes: the copy kernel behind the step's host<->device transfers -- device <- pinned host, pinned host <- device,
+    device <- device; sizes that are not multiples of 16 and pointers that are not 16-byte aligned take the byte path."""
+    rs = np.random.RandomState(3)
+    for n, off in ((1, 0), (15, 0), (16, 0), (28728, 0), (1800000, 0), (1000, 4), (4099, 1)):
+        src = torch.from_numpy(rs.randint(0, 256, n + off).astype(np.uint8)).pin_memory()
+        dev_buf = torch.zeros(n + off + 16, dtype=torch.uint8, device="cuda")
+        back = torch.zeros(n + off, dtype=torch.uint8).pin_memory()
+        ctx.call("radnet_copy_bytes", dev_buf[off:], src[off:], C.c_uint64(n))
+        ctx.call("radnet_copy_bytes", back[off:], dev_buf[off:], C.c_uint64(n))
+        dev2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ctx.call("radnet_copy_bytes", dev2, dev_buf[off:], C.c_uint64(n))
+        ctx.sync()
+        assert np.array_equal(back.numpy()[off:], src.numpy()[off:]), (n, off)
+        assert np.array_equal(dev2.cpu().numpy(), src.numpy()[off:]), (n, off)
+        assert int(dev_buf[off + n:].sum()) == 0 and int(back[:off].sum()) == 0          # nothing written outside the range
+    assert ctx.lib.radnet_copy_bytes(ctx.h, None, None, C.c_uint64(0)) == 0             # empty copy: no launch, no error
