@@ -277,13 +277,17 @@ def resize_cubic(img, new_w, new_h, to_host=True, ctx=None):
     result stays a device tensor (an image already at the target size is just uploaded)."""
     import torch
     from radnet_hip import runtime as rt
-    ctx = rt.default_context() if ctx is None else ctx          # a lane's context: the kernel goes to that lane's stream
-    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
-    if not to_host and (new_h, new_w) == tuple(img.shape[:2]):
-        return src
-    dst = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
-    ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], dst, new_h, new_w, img.shape[2])
-    return dst if not to_host else dst.cpu().numpy()
+    own = ctx is None
+    ctx = rt.default_context() if own else ctx                  # a lane's context: the kernel goes to that lane's stream
+    side = rt.thread_stream() if own else None                  # a worker thread resizes on its own stream (BackgroundFeed)
+    import contextlib
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
+        if not to_host and (new_h, new_w) == tuple(img.shape[:2]):
+            return src
+        dst = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
+        ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], dst, new_h, new_w, img.shape[2])
+        return dst if not to_host else dst.cpu().numpy()
 
 
 class _ConfigUnpickler(pickle.Unpickler):

@@ -7,16 +7,32 @@ import torch
 
 from . import lib as L
 
+import threading
+
 _ctx = None
 _scratch = {}
+_local = threading.local()
 
 
 def default_context():
-    """One radnet context on the current CUDA device (created on first use; raises without an MI355X)."""
+    """One radnet context on the current CUDA device (created on first use; raises without an MI355X).  The main thread's
+    context runs on the stream that was current when it was created; any other thread (data_feed.BackgroundFeed's worker
+    resizing tiles) gets a context of its own on a stream of its own -- a context is not shared between threads, and the
+    worker's device work must not queue behind the train step's."""
     global _ctx
-    if _ctx is None:
-        _ctx = L.Context(torch.cuda.current_device() if torch.cuda.is_available() else 0)
-    return _ctx
+    if threading.current_thread() is threading.main_thread():
+        if _ctx is None:
+            _ctx = L.Context(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        return _ctx
+    if getattr(_local, "ctx", None) is None:
+        _local.stream = torch.cuda.Stream()
+        _local.ctx = L.Context(torch.cuda.current_device(), stream_handle=_local.stream.cuda_stream)
+    return _local.ctx
+
+
+def thread_stream():
+    """The HIP stream of this thread's default context (None on the main thread: torch's current stream)."""
+    return getattr(_local, "stream", None) if threading.current_thread() is not threading.main_thread() else None
 
 
 def scratch(name, nbytes):

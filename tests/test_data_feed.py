@@ -191,3 +191,54 @@ def test_brightness_matches_reference_outputs():
             assert int(np.random.randint(0, 2 ** 31 - 1)) == int(g["c%d_s%d_after" % (ci, si)]), (ci, si)
             changed += int(not np.array_equal(out, img))
     assert changed >= 9                          # the in-range images really were shifted
+
+
+def test_background_feed_same_samples_and_error_passing():
+    """BackgroundFeed: the worker thread yields exactly the feed's samples, in order, ahead of the consumer; refuses a feed on the
+    global random stream; passes the worker's exception on; close() ends a worker blocked on a full queue."""
+    import time
+    C = Config()
+    C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, False
+    C.img_types = ["rgb"]
+    data, imgs = dataset(3, [(640, 480), (300, 300), (500, 620)])
+    cc = {c: 1 for c in CLASSES}
+    ident = lambda img, w, h: np.ascontiguousarray(img[:h, :w]) if img.shape[:2] != (h, w) else img      # host stand-in for the device resize
+    load = lambda d, t: imgs[d["filepath"]]
+
+    def take(it, n):
+        out = []
+        for s in it:
+            out.append((s["filepath"], s["width"], s["height"], [tuple(sorted(b.items())) for b in s["bboxes"]], int(s["img"].astype(np.int64).sum())))
+            if len(out) == n:
+                break
+        return out
+
+    ref = take(iter(F.TileFeed([dict(d) for d in data], C, cc, load, rng=np.random.RandomState(5), resize=ident, noise_rng=np.random.default_rng(2))), 12)
+    bg = F.BackgroundFeed(F.TileFeed([dict(d) for d in data], C, cc, load, rng=np.random.RandomState(5), resize=ident, noise_rng=np.random.default_rng(2)), depth=4)
+    time.sleep(0.3)                                  # the worker runs ahead on its own
+    assert bg._q.qsize() >= 1
+    got = take(bg, 12)
+    bg.close()
+    assert got == ref and len(ref) == 12
+    assert not bg._thread.is_alive()
+    with pytest.raises(ValueError):
+        F.BackgroundFeed(F.TileFeed([dict(d) for d in data], C, cc, load, resize=ident))         # global stream
+
+    def broken():
+        yield {"n": 1}
+        raise KeyError("decoder failed")
+
+    class G:                                          # any iterable with a private stream
+        rng = np.random.RandomState(1)
+        def __iter__(self):
+            return broken()
+
+    b2 = F.BackgroundFeed(G(), depth=2)
+    assert next(b2) == {"n": 1}
+    with pytest.raises(KeyError):
+        next(b2)
+    b2.close()
+    val = F.BackgroundFeed(F.TileFeed([dict(d) for d in data], C, cc, load, train_mode=False, rng=np.random.RandomState(5), resize=ident), depth=3)
+    n = len(list(val))                                # a finite feed ends the iteration
+    assert n == len(list(F.TileFeed([dict(d) for d in data], C, cc, load, train_mode=False, rng=np.random.RandomState(5), resize=ident))) > 0
+    val.close()

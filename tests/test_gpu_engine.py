@@ -486,3 +486,51 @@ def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
     finally:
         eng.set_weights(P)                                                  # module-scoped engine: restore
         eng.head_arena.g.zero_()
+
+
+def test_background_feed_drives_training_with_the_device_resize_on_its_own_stream():
+    """data_feed.BackgroundFeed: tiles cropped, augmented (default Config: everything on) and resized -- on the device, from the
+    worker thread, through that thread's own context and HIP stream -- beside the train step.  Same samples as the in-line feed
+    (private random streams, seeded noise), and a short training run over them finishes with finite losses."""
+    from faster_rcnn import data_feed as F
+    from faster_rcnn.config import Config
+    from oracle import dense
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size, C.tile_size, C.tile_overlap, C.balanced_classes = 300, 300, 150, False
+    rs = np.random.RandomState(9)
+    classes = [k for k in C.class_mapping if k != "bg"]
+    data, imgs = [], {}
+    for i, (w, h) in enumerate([(640, 480), (500, 700)]):
+        boxes = []
+        for j in range(8):
+            bw, bh = int(rs.randint(50, 140)), int(rs.randint(50, 140))
+            x1, y1 = int(rs.randint(0, w - bw)), int(rs.randint(0, h - bh))
+            boxes.append({"class": classes[j % len(classes)], "x1": x1, "x2": x1 + bw, "y1": y1, "y2": y1 + bh})
+        data.append({"filepath": "img%d" % i, "width": w, "height": h, "bboxes": boxes})
+        imgs["img%d" % i] = rs.randint(1, 256, (h, w, 3)).astype(np.uint8)
+    cc = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in classes}
+    mk = lambda: F.TileFeed([dict(d) for d in data], C, cc, lambda d, t: imgs[d["filepath"]], rng=np.random.RandomState(4),
+                            noise_rng=np.random.default_rng(6))
+    inline = []
+    for s in mk():
+        inline.append(s)
+        if len(inline) == 8:
+            break
+    bg = F.BackgroundFeed(mk(), depth=4)
+    try:
+        threaded = [next(bg) for _ in range(8)]
+        for a, b in zip(inline, threaded):
+            assert a["bboxes"] == b["bboxes"] and np.array_equal(a["img"], b["img"])
+        eng = FasterRCNNEngine(C, autotune=2)
+        eng.set_weights(dense.init_params(seed=3))
+        np.random.seed(5)
+        ts = TrainStep(eng)
+        seen = []
+        n = F.run_training(ts, bg, 6, lookahead=2, on_step=lambda k, t: seen.append(t.losses()))
+        assert n == 6
+        assert all(lo["dropped"] == 1 or np.isfinite(lo["rpn_cls"]) for lo in seen), seen
+    finally:
+        bg.close()
+    assert not bg._thread.is_alive()
