@@ -411,8 +411,10 @@ def main():
         exec_fl = tot_fl - (wfl * (1.0 - winograd_executed_share(eng)) if wn else 0.0)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": (committed_pmc_traffic() or {}).get("bytes"), "traffic_detail": committed_pmc_traffic(), "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32; 3x3 layers via Winograd transforms)",
-                "schedule": "one lane, launches isolated (each GEMM launch alone on the chip between two HIP events); `value` is measured on the "
-                            "pipelined schedule, where lanes overlap -- gemm_ms_per_image here may exceed ms_per_step",
+                "schedule": "one lane, launches isolated (each GEMM launch alone on the chip, timed from its own dispatch: hipExtLaunchKernelGGL "
+                            "start / stop events = the kernel's begin and end, as rocprofv3 --kernel-trace reports them; Winograd layers: two marker "
+                            "events around their three kernels); `value` is measured on the pipelined schedule, where lanes overlap -- "
+                            "gemm_ms_per_image here may exceed ms_per_step",
                 "winograd_credit": "Winograd layers are timed per layer (3 kernels) and credited the algorithmic 2*M*N*9C flops, not the 4x (F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer they execute",
                 "executed_tflops": exec_fl / max(tot_ms, 1e-9) / 1e9, "executed_frac": exec_fl / max(tot_ms, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,

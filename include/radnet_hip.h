@@ -68,10 +68,12 @@ int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);
 /* With radnet_force_config active: waves per workgroup of the forward / dgrad kernel (4, or 8 = every K tile halved
  * between two wave grids and summed through LDS); 0 = default (4). */
 int radnet_force_waves(radnet_ctx* ctx, int waves);
-/* Per-launch timing of the LAST launched conv/GEMM kernel family with HIP events on the ctx stream
- * (bench.py's roofline leg).  enable=1 starts recording; radnet_timing_read returns accumulated
- * milliseconds and launch count since the last reset for kernel class `cls` (0 fwd, 1 dgrad, 2 wgrad, 3 Winograd 3x3 LAYERS
- * of a program: transforms + 16 GEMMs timed as one unit and credited the layer's algorithmic 2*M*N*9C flops). */
+/* Per-launch timing of the conv/GEMM kernel families with HIP events on the ctx stream (bench.py's roofline leg).
+ * enable=1 starts recording; radnet_timing_read returns accumulated milliseconds and launch count since the last reset for
+ * kernel class `cls`: 0 fwd, 1 dgrad, 2 wgrad, 4 dgrad + wgrad in one launch -- each launch timed from its own dispatch
+ * (hipExtLaunchKernelGGL start / stop events: the kernel's begin and end, what rocprofv3 --kernel-trace reports) --, and
+ * 3 Winograd 3x3 LAYERS of a program: transforms + batched GEMMs bracketed by two marker events as one unit (that bracket
+ * includes the markers' dispatch latency, ~5 us) and credited the layer's algorithmic 2*M*N*9C flops. */
 int radnet_timing_enable(radnet_ctx* ctx, int enable);
 int radnet_timing_read(radnet_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops);
 int radnet_timing_reset(radnet_ctx* ctx);

@@ -163,6 +163,29 @@ void radnet_timing_end(radnet_ctx* ctx, int cls, double flops) {
   ctx->n_pending = i + 1;
 }
 
+void radnet_timing_arm(radnet_ctx* ctx) {
+  ctx->arm0 = ctx->arm1 = nullptr;
+  if (!ctx->timing) return;
+  if (ctx->n_pending >= radnet_ctx::kMaxPending) resolve_pending(ctx);
+  int i = ctx->n_pending;
+  if (i >= ctx->n_events_alloc) {
+    (void)hipEventCreate(&ctx->pend0[i]);
+    (void)hipEventCreate(&ctx->pend1[i]);
+    ctx->n_events_alloc = i + 1;
+  }
+  ctx->arm0 = ctx->pend0[i];
+  ctx->arm1 = ctx->pend1[i];
+}
+
+void radnet_timing_end_armed(radnet_ctx* ctx, int cls, double flops) {
+  if (!ctx->timing || !ctx->arm0) return;
+  int i = ctx->n_pending;
+  ctx->pend_cls[i] = cls;
+  ctx->pend_flops[i] = flops;
+  ctx->n_pending = i + 1;
+  ctx->arm0 = ctx->arm1 = nullptr;
+}
+
 extern "C" int radnet_timing_enable(radnet_ctx* ctx, int enable) {
   if (!ctx) return RADNET_ERR_ARG;
   if (!enable) resolve_pending(ctx);

@@ -27,9 +27,17 @@
 //     from limiting; what matters is filling 256 CUs at batch 1 -- tile shape, K slices, workgroup order and waves per
 //     workgroup are measured per problem shape (run_igemm).
 #include "radnet_internal.h"
+#include <hip/hip_ext.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One launch, timed from its own dispatch when an event pair is armed (bench.py's roofline leg), plain otherwise.
+#define RADNET_LAUNCH(kernel, grid, block, shmem, st, e0, e1, ...)                                                  \
+  do {                                                                                                              \
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, e0, e1, 0, __VA_ARGS__);                          \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                           \
+  } while (0)
 
 namespace {
 
@@ -1118,21 +1126,21 @@ const int* get_row_table(radnet_ctx* ctx, const radnet_conv_desc* d) {
 }
 
 template <int BMODE, bool SMALLC, int WAVES>
-void launch_igemm_w(hipStream_t st, const GemmArgs& g, const TileChoice& tc, dim3 grid) {
+void launch_igemm_w(hipStream_t st, const GemmArgs& g, const TileChoice& tc, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
   dim3 block(64 * WAVES);
   // (capping workgroups per CU with extra dynamic LDS was measured: 7-25 % slower on every layer -- co-residency wins)
-  if (tc.bm == 128 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
-  else if (tc.bm == 128 && tc.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
-  else if (tc.bm == 64 && tc.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<64, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, g);
+  if (tc.bm == 128 && tc.bn == 128) RADNET_LAUNCH((conv_igemm_kernel<128, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
+  else if (tc.bm == 128 && tc.bn == 64) RADNET_LAUNCH((conv_igemm_kernel<128, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
+  else if (tc.bm == 64 && tc.bn == 128) RADNET_LAUNCH((conv_igemm_kernel<64, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
+  else RADNET_LAUNCH((conv_igemm_kernel<64, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
 }
 
 template <int BMODE, bool SMALLC>
-void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n_units) {
+void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n_units, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), g.batch > 1 ? g.batch : 1);
   if (g.units != nullptr) grid = dim3(n_units, 1, 1);
-  if (tc.waves == 8) launch_igemm_w<BMODE, SMALLC, 8>(st, g, tc, grid);
-  else launch_igemm_w<BMODE, SMALLC, 4>(st, g, tc, grid);
+  if (tc.waves == 8) launch_igemm_w<BMODE, SMALLC, 8>(st, g, tc, grid, e0, e1);
+  else launch_igemm_w<BMODE, SMALLC, 4>(st, g, tc, grid, e0, e1);
 }
 
 // radnet_conv_bwd: the final launch of run_igemm (dgrad) / run_wgrad lands here instead of on the stream while
@@ -1214,10 +1222,10 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       return RADNET_OK;
     }
     if (bmode == 0) {
-      if (smallc) launch_igemm<0, true>(ctx->stream, g, t, n_units);
-      else launch_igemm<0, false>(ctx->stream, g, t, n_units);
+      if (smallc) launch_igemm<0, true>(ctx->stream, g, t, n_units, ctx->arm0, ctx->arm1);
+      else launch_igemm<0, false>(ctx->stream, g, t, n_units, ctx->arm0, ctx->arm1);
     } else {
-      launch_igemm<1, false>(ctx->stream, g, t, n_units);
+      launch_igemm<1, false>(ctx->stream, g, t, n_units, ctx->arm0, ctx->arm1);
     }
     RADNET_CHECK_LAUNCH(ctx, "conv_igemm");
     return RADNET_OK;
@@ -1277,14 +1285,14 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   } else {
     tc = choose_tiles(g.M, g.N, g.K, ctx->ws != nullptr && g.batch <= 1);
   }
-  radnet_timing_begin(ctx);
+  radnet_timing_arm(ctx);
   int rc = launch(tc);
   if (rc == RADNET_ERR_UNSUPPORTED && ctx->force_a <= 0) {      // a shared / loaded choice whose slabs exceed THIS context's workspace
     tc.splits = tc.splits < 0 ? -1 : 1;
     rc = launch(tc);
   }
   if (rc != RADNET_OK) return rc;
-  radnet_timing_end(ctx, cls, 2.0 * g.M * g.N * g.K * (g.batch > 1 ? g.batch : 1));
+  radnet_timing_end_armed(ctx, cls, 2.0 * g.M * g.N * g.K * (g.batch > 1 ? g.batch : 1));
   return RADNET_OK;
 }
 
@@ -1394,10 +1402,10 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
       pc->flops += 2.0 * g.M * g.N * g.K;
       return RADNET_OK;
     }
-    if (bmk == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, g);
-    else if (bmk == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, g);
-    else if (bmk == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, ctx->stream, g);
+    if (bmk == 128 && bn == 128) RADNET_LAUNCH((conv_wgrad_kernel<128, 128>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g);
+    else if (bmk == 128 && bn == 64) RADNET_LAUNCH((conv_wgrad_kernel<128, 64>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g);
+    else if (bmk == 64 && bn == 128) RADNET_LAUNCH((conv_wgrad_kernel<64, 128>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g);
+    else RADNET_LAUNCH((conv_wgrad_kernel<64, 64>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g);
     RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
     return RADNET_OK;
   };
@@ -1461,7 +1469,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
       while (tiles * splits < 2 * kNumCU && nmt / (splits * 2) >= 4 && splits < 16) splits *= 2;
     }
   }
-  radnet_timing_begin(ctx);
+  radnet_timing_arm(ctx);
   {
     // bias gradient in the same launch (the measurement launches above ran without it); atomics need zeros to add to
     g.db = d->db;
@@ -1470,7 +1478,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     if (rc != RADNET_OK) return rc;
   }
   RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
-  radnet_timing_end(ctx, 2, 2.0 * g.M * g.N * g.K * (batch > 1 ? batch : 1));
+  radnet_timing_end_armed(ctx, 2, 2.0 * g.M * g.N * g.K * (batch > 1 ? batch : 1));
   return RADNET_OK;
 }
 
@@ -1500,10 +1508,10 @@ extern "C" int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
     return rc != RADNET_OK ? rc : radnet_conv_dgrad(ctx, d);
   }
   PairMap pm{pc.ax * pc.ay, pc.wx * pc.wy * pc.wz, pc.ax, pc.ay, pc.wx, pc.wy};
-  radnet_timing_begin(ctx);
-  hipLaunchKernelGGL(conv_bwd_pair_kernel, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, pc.ga, pc.gw, pm);
+  radnet_timing_arm(ctx);
+  RADNET_LAUNCH(conv_bwd_pair_kernel, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, pc.ga, pc.gw, pm);
   RADNET_CHECK_LAUNCH(ctx, "conv_bwd_pair");
-  radnet_timing_end(ctx, 4, pc.flops);
+  radnet_timing_end_armed(ctx, 4, pc.flops);
   return RADNET_OK;
 }
 

@@ -81,6 +81,7 @@ struct radnet_ctx {
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   radnet_timing_slot slots[5];      // 0 fwd, 1 dgrad, 2 wgrad, 3 Winograd layers of a program, 4 dgrad + wgrad of a layer in one launch
+  hipEvent_t arm0 = nullptr, arm1 = nullptr;      // event pair of the launch being timed (radnet_timing_arm), or null
   void* pair_capture = nullptr;     // conv_mfma.hip: radnet_conv_bwd collects the two launches of a layer here instead of issuing them
   // pending (not yet resolved) event pairs are resolved lazily to avoid a sync per launch
   static constexpr int kMaxPending = 4096;
@@ -118,6 +119,11 @@ struct radnet_ctx {
 // timing helpers (api.cpp)
 void radnet_timing_begin(radnet_ctx* ctx);
 void radnet_timing_end(radnet_ctx* ctx, int cls, double flops);
+// Kernel-exact form for a single launch: arm() hands out the event pair, the launch site passes it to hipExtLaunchKernelGGL
+// (start / stop taken from the dispatch itself, as rocprofv3 reads them), end_armed() books it.  The marker-event form above
+// brackets several launches (a Winograd layer) and includes the dispatch latency of its two markers (~5 us per bracket).
+void radnet_timing_arm(radnet_ctx* ctx);
+void radnet_timing_end_armed(radnet_ctx* ctx, int cls, double flops);
 
 static inline int radnet_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
