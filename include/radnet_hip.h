@@ -286,6 +286,13 @@ int radnet_copy_bytes(radnet_ctx* ctx, void* dst, const void* src, uint64_t byte
  * Parity unpinned (OpenCV absent offline). */
 int radnet_resize_bicubic_u8(radnet_ctx* ctx, const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh,
                              int32_t dw, int32_t channels);
+/* cv2.warpAffine(src, M, (dw, dh)) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) for uint8 HWC tiles: the +-3 degree rotation
+ * and the shear of the train-time augmentation (augmentation.py:158-271).  The caller inverts M and passes the inverse map's
+ * per-column and per-row terms in 10-bit fixed point, rounded in float64 as OpenCV does: col_tab = {adelta[dw], bdelta[dw]},
+ * row_tab = {x0[dh], y0[dh]} (device int32 arrays; faster_rcnn/augmentation.py:warp_tables builds them).  Bit-identical to that
+ * module's NumPy restatement; against OpenCV itself unpinned (absent here). */
+int radnet_warp_affine_u8(radnet_ctx* ctx, const uint8_t* src, int32_t sh, int32_t sw, int32_t channels, uint8_t* dst, int32_t dh,
+                          int32_t dw, const int32_t* col_tab, const int32_t* row_tab);
 int radnet_fill_zero(radnet_ctx* ctx, void* p, uint64_t bytes);
 /* y = x * alpha (n floats); used to average gradients after all-reduce */
 int radnet_scale(radnet_ctx* ctx, float* x, int64_t n, float alpha);

@@ -69,3 +69,47 @@ extern "C" int radnet_resize_bicubic_u8(radnet_ctx* ctx, const uint8_t* src, int
   RADNET_CHECK_LAUNCH(ctx, "resize_bicubic_u8");
   return RADNET_OK;
 }
+
+// ---- affine warp of uint8 HWC tiles: the arbitrary-angle rotation and the shear of the train-time augmentation -------------
+// (augmentation.py:158-271: cv2.warpAffine with its defaults -- bilinear, constant border 0).  PARITY UNPINNED against OpenCV
+// like the resize above; bit-for-bit equal to the NumPy restatement faster_rcnn/augmentation.py:warp_affine_u8, which documents
+// the arithmetic: the host inverts the matrix and rounds the per-column / per-row terms of the inverse map to 10-bit fixed
+// point in float64 (x_tab, y_tab: what OpenCV precomputes too), the kernel adds them, splits 1/32-pixel fractions off, and mixes
+// the four neighbours (0 outside the image) with the integer weights 32 (32 - fx)(32 - fy) ..., rounding (sum + 2^14) >> 15.
+namespace {
+__global__ void __launch_bounds__(256) warp_affine_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int ch, uint8_t* __restrict__ dst, int dh,
+                                                             int dw, const int* __restrict__ col_tab, const int* __restrict__ row_tab) {
+  const unsigned total = (unsigned)dh * (unsigned)dw;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const unsigned y = idx / (unsigned)dw, x = idx - y * (unsigned)dw;
+    // col_tab = {adelta[dw], bdelta[dw]}, row_tab = {x0[dh], y0[dh]} (x0 / y0 carry the half-step rounding offset)
+    const int X = (row_tab[y] + col_tab[x]) >> 5, Y = (row_tab[dh + y] + col_tab[dw + x]) >> 5;
+    int sx = X >> 5, sy = Y >> 5;
+    sx = min(max(sx, -32768), 32767);
+    sy = min(max(sy, -32768), 32767);
+    const int fx = X & 31, fy = Y & 31;
+    const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+    const bool y0in = (unsigned)sy < (unsigned)sh, y1in = (unsigned)(sy + 1) < (unsigned)sh;
+    const bool x0in = (unsigned)sx < (unsigned)sw, x1in = (unsigned)(sx + 1) < (unsigned)sw;
+    for (int c = 0; c < ch; ++c) {
+      const int p00 = (y0in && x0in) ? src[((long long)sy * sw + sx) * ch + c] : 0;
+      const int p01 = (y0in && x1in) ? src[((long long)sy * sw + sx + 1) * ch + c] : 0;
+      const int p10 = (y1in && x0in) ? src[((long long)(sy + 1) * sw + sx) * ch + c] : 0;
+      const int p11 = (y1in && x1in) ? src[((long long)(sy + 1) * sw + sx + 1) * ch + c] : 0;
+      dst[(long long)idx * ch + c] = (uint8_t)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int radnet_warp_affine_u8(radnet_ctx* ctx, const uint8_t* src, int32_t sh, int32_t sw, int32_t channels, uint8_t* dst, int32_t dh,
+                                     int32_t dw, const int32_t* col_tab, const int32_t* row_tab) {
+  if (!ctx || !src || !dst || !col_tab || !row_tab || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || channels <= 0) return RADNET_ERR_ARG;
+  const long long total = (long long)dh * dw;
+  if (total >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "warp_affine: %lld output pixels", total);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(warp_affine_u8_kernel, dim3(blocks), dim3(256), 0, ctx->stream, src, sh, sw, channels, dst, dh, dw, col_tab, row_tab);
+  RADNET_CHECK_LAUNCH(ctx, "warp_affine_u8");
+  return RADNET_OK;
+}

@@ -48,12 +48,11 @@ def _sat_i32(v):
     return np.clip(np.rint(v), -2 ** 31, 2 ** 31 - 1).astype(np.int64)          # saturate_cast<int>(double): round half to even
 
 
-def warp_affine_u8(src, mat, dsize):
-    """cv2.warpAffine(src, mat, dsize) with its defaults (INTER_LINEAR, BORDER_CONSTANT, border value 0) for uint8 HWC.
-    `mat` maps source to destination and is inverted first; destination pixel (x, y) samples the source at
-    ((X0[y] + adelta[x]) >> 5, ...) in 1/32-pixel units, X0 / adelta being the inverse map in 10-bit fixed point with half a
-    1/32 step of rounding offset; the four neighbours (0 outside the image) are mixed with weights
-    32 (32 - fx)(32 - fy) ... that sum to 2^15, rounded: (sum + 2^14) >> 15."""
+def warp_tables(mat, dsize):
+    """The inverse map of cv2.warpAffine in 10-bit fixed point, as OpenCV precomputes it: per destination column
+    adelta[x] = round(A00 x 1024), bdelta[x] = round(A10 x 1024); per destination row x0[y] = round((A01 y + A02) 1024) + 16,
+    y0[y] = round((A11 y + A12) 1024) + 16 -- A the inverse of `mat`, 16 = half a 1/32-pixel step.  Destination (x, y) then reads
+    the source at ((x0[y] + adelta[x]) >> 5, (y0[y] + bdelta[x]) >> 5) in 1/32 pixels.  int64 arrays (every entry fits int32)."""
     dw, dh = int(dsize[0]), int(dsize[1])
     m = np.array(mat, dtype=np.float64).reshape(2, 3).copy()
     det = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
@@ -68,6 +67,16 @@ def warp_affine_u8(src, mat, dsize):
     adelta, bdelta = _sat_i32(m[0, 0] * xs * ab_scale), _sat_i32(m[1, 0] * xs * ab_scale)
     x0 = _sat_i32((m[0, 1] * ys + m[0, 2]) * ab_scale) + half_step
     y0 = _sat_i32((m[1, 1] * ys + m[1, 2]) * ab_scale) + half_step
+    return adelta, bdelta, x0, y0
+
+
+def warp_affine_u8(src, mat, dsize):
+    """cv2.warpAffine(src, mat, dsize) with its defaults (INTER_LINEAR, BORDER_CONSTANT, border value 0) for uint8 HWC.
+    `mat` maps source to destination and is inverted first (warp_tables); the four neighbours of the 1/32-pixel source position
+    (0 outside the image) are mixed with weights 32 (32 - fx)(32 - fy) ... that sum to 2^15, rounded: (sum + 2^14) >> 15.
+    The device form of the same arithmetic is radnet_warp_affine_u8 (RADNet.warp_affine_device), bit-identical."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    adelta, bdelta, x0, y0 = warp_tables(mat, dsize)
     X = (x0[:, None] + adelta[None, :]) >> 5
     Y = (y0[:, None] + bdelta[None, :]) >> 5
     sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
@@ -205,7 +214,7 @@ def ninety_degree_rotation(img, bboxes, verbose=False, rng=np.random):
     return img, bboxes
 
 
-def any_degree_rotation(img, bboxes, verbose=False, rng=np.random):
+def any_degree_rotation(img, bboxes, verbose=False, rng=np.random, warp=None):
     """augmentation.py:158-232: one draw, U(-3, 3) degrees about (w // 2, h // 2); the canvas grows to hold the rotated image,
     each box becomes the axis-aligned hull of its four rotated corners, the result is strapped to its non-black extent and
     the boxes clipped to that (dropped when less than half is left)."""
@@ -218,7 +227,7 @@ def any_degree_rotation(img, bboxes, verbose=False, rng=np.random):
     new_w, new_h = int(h * s + w * c), int(h * c + w * s)
     mat[0, 2] += new_w / 2 - cx
     mat[1, 2] += new_h / 2 - cy
-    img = warp_affine_u8(img, mat, (new_w, new_h))
+    img = (warp or warp_affine_u8)(img, mat, (new_w, new_h))
     if arr.ndim == 2:
         x1, y1, x2, y2 = (arr[:, i] for i in range(4))
         px = np.stack((x1, x1 + (x2 - x1), x1, x2), 1)                    # corner order of the reference: tl, tr, bl, br
@@ -236,7 +245,7 @@ def any_degree_rotation(img, bboxes, verbose=False, rng=np.random):
     return img, bboxes
 
 
-def shear(img, bboxes, verbose=False, rng=np.random):
+def shear(img, bboxes, verbose=False, rng=np.random, warp=None):
     """augmentation.py:234-271: one draw, U(-0.3, 0.3); x' = x + |f| y on a canvas widened by |f| h (negative factors: the
     same between two horizontal flips); box x coordinates move by int(|f| y) of their own corner, then the strap offset."""
     f = rng.uniform(-0.3, 0.3)
@@ -246,7 +255,7 @@ def shear(img, bboxes, verbose=False, rng=np.random):
     arr = _boxes_array(bboxes)
     if arr.ndim == 2:
         arr[:, [0, 2]] += (arr[:, [1, 3]] * abs(f)).astype(int)
-    img = warp_affine_u8(img, np.array([[1, abs(f), 0], [0, 1, 0]], dtype=np.float64), (int(w + abs(f * h)), h))
+    img = (warp or warp_affine_u8)(img, np.array([[1, abs(f), 0], [0, 1, 0]], dtype=np.float64), (int(w + abs(f * h)), h))
     row_min, row_max, col_min, col_max = strap_img(img)
     img = img[row_min:row_max, col_min:col_max, :]
     if arr.ndim == 2:
@@ -332,10 +341,11 @@ def poisson_noise(img, bboxes, img_type, verbose=False, rng=np.random, noise_rng
     return _noisy(img, img_type, "poisson", noise_rng), bboxes
 
 
-def augment(img_data, img, config, augment=True, verbose=False, rng=np.random, noise_rng=None):
+def augment(img_data, img, config, augment=True, verbose=False, rng=np.random, noise_rng=None, warp=None):
     """augmentation.py:481-533: a deep copy of img_data with the boxes of the augmented image, and the image.  One coin per
     enabled switch, in the reference's order and with its thresholds (shear: 0.25, the others 0.5); the noise family
-    draws a second time for which of its four members runs."""
+    draws a second time for which of its four members runs.  warp: the affine warp of the rotation and the shear -- None = the
+    NumPy form above, or the bit-identical device kernel (RADNet.warp_affine_device; what TileFeed uses with the device resize)."""
     for k in ("filepath", "bboxes", "width", "height"):
         assert k in img_data
     out = copy.deepcopy(img_data)
@@ -348,9 +358,9 @@ def augment(img_data, img, config, augment=True, verbose=False, rng=np.random, n
         if C.use_90_rotations and rng.random() < 0.5:
             img, boxes = ninety_degree_rotation(img, boxes, verbose, rng=rng)
         if C.use_rotations and rng.random() < 0.5:
-            img, boxes = any_degree_rotation(img, boxes, verbose, rng=rng)
+            img, boxes = any_degree_rotation(img, boxes, verbose, rng=rng, warp=warp)
         if C.use_shear and rng.random() < 0.25:
-            img, boxes = shear(img, boxes, verbose, rng=rng)
+            img, boxes = shear(img, boxes, verbose, rng=rng, warp=warp)
         if C.use_brightness and rng.random() < 0.5:
             img, boxes = brightness(np.ascontiguousarray(img), boxes, verbose, rng=rng)
         if C.use_noise and rng.random() < 0.5:

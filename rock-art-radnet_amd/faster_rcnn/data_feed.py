@@ -37,10 +37,10 @@ def brightness(img, rng=np.random):
     return augmentation.brightness(img, [], rng=rng)[0]
 
 
-def augment_geometric(img_data, img, C, rng=np.random, noise_rng=None):
+def augment_geometric(img_data, img, C, rng=np.random, noise_rng=None, warp=None):
     """augmentation.augment (augmentation.py:481-533) for the feed: every switch of the reference, its draw order; returns
     (img_data copy with the augmented boxes / width / height, image)."""
-    return augmentation.augment(img_data, img, C, augment=True, rng=rng, noise_rng=noise_rng)
+    return augmentation.augment(img_data, img, C, augment=True, rng=rng, noise_rng=noise_rng, warp=warp)
 
 
 def get_data(annot_path, data_path, img_types, load_image):
@@ -128,6 +128,10 @@ class TileFeed:
     def __init__(self, data, C, class_count, load_image, train_mode=True, rng=None, resize=None, noise_rng=None):
         self.data, self.C, self.load_image, self.train_mode = data, C, load_image, train_mode
         self.noise_rng = noise_rng                # numpy Generator of the noise augmentations' fields; None = unseeded, as scikit-image's
+        self.warp = None                          # rotation / shear warp: the device kernel beside the device resize, else NumPy
+        if resize is None and train_mode and (getattr(C, "use_rotations", False) or getattr(C, "use_shear", False)):
+            from .RADNet import warp_affine_device
+            self.warp = warp_affine_device
         self.rng = np.random if rng is None else rng
         self.selector = SampleSelector(class_count)
         self.resize = resize                      # (img, new_w, new_h) -> img; default: the device bicubic kernel
@@ -188,7 +192,7 @@ class TileFeed:
                     if balanced and sel.skip_tile_for_balanced_class(tile_data):
                         continue
                     if self.train_mode:
-                        tile_data, crop = augment_geometric(tile_data, crop, C, self.rng, self.noise_rng)
+                        tile_data, crop = augment_geometric(tile_data, crop, C, self.rng, self.noise_rng, self.warp)
                     done += 1
                     yield self._sample(crop, tile_data)
                 if C.include_full_img:
@@ -197,7 +201,7 @@ class TileFeed:
                     img = self._image(img_data, C.use_img_type)
                     full = copy.deepcopy(img_data)
                     if self.train_mode:
-                        full, img = augment_geometric(full, img, C, self.rng, self.noise_rng)
+                        full, img = augment_geometric(full, img, C, self.rng, self.noise_rng, self.warp)
                     yield self._sample(img, full)
             if not self.train_mode:
                 return

@@ -194,6 +194,7 @@ def load_library():
         "radnet_host_choice_round": (i64, [vp, vp, vp, vp, i64, vp, i64, vp, vp]),
         "radnet_preprocess_bgr": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "radnet_resize_bicubic_u8": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32]),
+        "radnet_warp_affine_u8": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
         "radnet_fill_zero": (C.c_int, [vp, vp, u64]),
         "radnet_copy_bytes": (C.c_int, [vp, vp, vp, C.c_uint64]),
         "radnet_program_run": (C.c_int, [vp, C.POINTER(Op), i32]),
