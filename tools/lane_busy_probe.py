@@ -22,9 +22,18 @@ from radnet_hip.trainer import TrainStep  # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     C = Config()
+    nccl1 = os.environ.get("RADNET_BENCH_REHEARSAL") == "nccl1"          # 1-rank RCCL group: the data-parallel structure of the step
+    if nccl1:
+        import torch.distributed as dist
+        from radnet_hip import trainer as _tr
+        _tr.FORCE_COLLECTIVES = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     eng = make_engine(C)
     eng.set_weights(synth.synthetic_weights(seed=3))
-    ts = TrainStep(eng)
+    ts = TrainStep(eng, defer_head_update=True if nccl1 else None)
     batch = bench.make_batch(0, 1, 600, 1000)
     look = ts.LOOKAHEAD
     for _ in range(2 * ts.NBUF + 6):
