@@ -284,10 +284,15 @@ def resize_cubic(img, new_w, new_h, to_host=True, ctx=None):
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).cuda()
         if not to_host and (new_h, new_w) == tuple(img.shape[:2]):
-            return src
-        dst = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
-        ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], dst, new_h, new_w, img.shape[2])
-        return dst if not to_host else dst.cpu().numpy()
+            out = src
+        else:
+            out = torch.empty((new_h, new_w, img.shape[2]), dtype=torch.uint8, device="cuda")
+            ctx.call("radnet_resize_bicubic_u8", src, img.shape[0], img.shape[1], out, new_h, new_w, img.shape[2])
+            if to_host:
+                return out.cpu().numpy()
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)          # a device result made on the worker's stream: its consumer's stream waits
+    return out
 
 
 def warp_affine_device(img, mat, dsize, ctx=None):
