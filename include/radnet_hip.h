@@ -68,6 +68,15 @@ int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices);
 /* With radnet_force_config active: waves per workgroup of the forward / dgrad kernel (4, or 8 = every K tile halved
  * between two wave grids and summed through LDS); 0 = default (4). */
 int radnet_force_waves(radnet_ctx* ctx, int waves);
+/* Reproducible reductions (default ON; the environment variable RADNET_DETERMINISTIC=0 sets the default of new contexts to
+ * off).  ON: every floating-point reduction that crosses workgroups -- the pixel splits of conv_wgrad / wgrad_batched /
+ * conv_bwd and their bias gradients, radnet_colsum's row blocks, radnet_roi_resize_bwd's overlapping RoIs, the loss sums of
+ * radnet_rpn_loss -- is handed to ONE workgroup that adds the partial results in index order, so a launch returns the same
+ * bits on every run and on every stream (TF's own GPU gradients, train.py:288/393, give no such guarantee; what this buys is
+ * that two schedules of the same training step can be compared bit for bit).  OFF: fp32 / fp64 atomics, whose order -- and
+ * therefore last bits -- change from run to run.  Split weight-gradient launches then keep their partial tiles in the
+ * workspace (radnet_set_workspace), from its end downwards; launch shapes whose partials do not fit are not used. */
+int radnet_set_deterministic(radnet_ctx* ctx, int enable);
 /* Per-launch timing of the conv/GEMM kernel families with HIP events on the ctx stream (bench.py's roofline leg).
  * enable=1 starts recording; radnet_timing_read returns accumulated milliseconds and launch count since the last reset for
  * kernel class `cls`: 0 fwd, 1 dgrad, 2 wgrad, 4 dgrad + wgrad in one launch -- each launch timed from its own dispatch
@@ -427,6 +436,9 @@ int radnet_comm_unique_id(char out128[128]);
 int radnet_comm_init(radnet_ctx* ctx, int32_t world, int32_t rank, const char id128[128]);
 int radnet_comm_destroy(radnet_ctx* ctx);
 int radnet_allreduce_grads(radnet_ctx* ctx, float* grads, int64_t count);
+/* Exchanges issued on this context so far (calls, fp32 elements): lets a caller check that every rank of a data-parallel job
+ * takes part in the same sequence of collectives, whatever path its own image took through radnet_train_step. */
+int radnet_comm_stats(radnet_ctx* ctx, int64_t* calls, int64_t* elements);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,11 @@ extern "C" int radnet_create(int device, void* hip_stream, radnet_ctx** out) {
   radnet_ctx* c = new radnet_ctx();
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
+  if (const char* e = getenv("RADNET_DETERMINISTIC")) c->deterministic = strcmp(e, "0") != 0;
+  if (hipMalloc((void**)&c->aux, kAuxBytes) != hipSuccess || hipMemset(c->aux, 0, kAuxBytes) != hipSuccess) {
+    delete c;
+    return RADNET_ERR_HIP;
+  }
   *out = c;
   return RADNET_OK;
 }
@@ -32,6 +37,7 @@ extern "C" void radnet_destroy(radnet_ctx* ctx) {
   }
   if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
   if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
+  if (ctx->aux) (void)hipFree(ctx->aux);
   delete ctx;
 }
 
@@ -58,6 +64,12 @@ extern "C" int radnet_set_autotune(radnet_ctx* ctx, int enable) {
 radnet_ctx::RowTables::~RowTables() {
   for (auto& kv : m)
     if (kv.second) (void)hipFree(kv.second);
+}
+
+extern "C" int radnet_set_deterministic(radnet_ctx* ctx, int enable) {
+  if (!ctx) return RADNET_ERR_ARG;
+  ctx->deterministic = enable ? 1 : 0;
+  return RADNET_OK;
 }
 
 extern "C" int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner) {

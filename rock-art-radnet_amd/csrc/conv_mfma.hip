@@ -766,6 +766,13 @@ struct WgradArgs {
   unsigned x_bytes, dy_bytes;
   int batch, splits;     // batch > 1: blockIdx.z = problem * splits + split (radnet_wgrad_batched)
   long long x_bstride, dy_bstride, dw_bstride;   // floats between consecutive problems
+  // Ordered reduction of a split launch (radnet_ctx::deterministic): the splits write their partial tiles as slabs, the last
+  // one to arrive at a tile sums them in split order -- the forward kernel's in-launch split-K protocol.  slabs == null:
+  // fp32 atomics (run-to-run differences in the last bits).
+  float* slabs;          // [tile][split][BMK*BN], then the bias partials [n tile][split][BN]
+  unsigned* counters;    // arrival counter per tile (zero outside a launch)
+  int accumulate;        // ordered form: 1 = add the sum to dw's contents, 0 = store it
+  int tiles_x, tiles_y;  // grid.x, grid.y of the launch (the pair kernel has a grid of its own)
 };
 
 template <int BMK, int BN>
@@ -922,6 +929,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __res
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] += accs[c][i][j];
 
+  const bool ordered = g.slabs != nullptr;      // uniform for the launch
+  float4 bias_t = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_bias) {             // uniform per workgroup; the staging array is free after the loop's last barrier
     float4* red = reinterpret_cast<float4*>(lds);
     red[tid] = csum;
@@ -932,12 +941,90 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __res
         const float4 u = red[tid + q * CPRB];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
+      bias_t = t;
       const int n = n0 + tid * 4;
-      if (n < g.N) {           // N is a multiple of 4
+      if (!ordered && n < g.N) {           // N is a multiple of 4
         atomicAdd(g.db + n, t.x);
         atomicAdd(g.db + n + 1, t.y);
         atomicAdd(g.db + n + 2, t.z);
         atomicAdd(g.db + n + 3, t.w);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (ordered) {
+    // Same hand-off as the forward kernel's split-K (see there): sc1 slab stores drained before the barrier, one relaxed
+    // agent-scope ticket per workgroup, the last arriver reads every slab back with sc1 loads and adds them in split order,
+    // so the sum does not depend on which split came last.  The bias partials of the first k tile's workgroups travel the
+    // same way.
+    const unsigned tile = ((unsigned)bp * (unsigned)g.tiles_y + bid_y) * (unsigned)g.tiles_x + bid_x;
+    const unsigned lane_off = (unsigned)((wave * TM * TN * 64 + lane) * 16) * 4u;
+    const size_t total_tiles = (size_t)(g.batch > 1 ? g.batch : 1) * g.tiles_y * g.tiles_x;
+    const __amdgpu_buffer_rsrc_t rslab = make_rsrc(g.slabs + ((size_t)tile * g.splits + zsplit) * (BMK * BN), BMK * BN * 4u);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          buf_store4_sc1(rslab, lane_off + (unsigned)(((i * TN + j) * 64 * 16 + q * 4) * 4),
+                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
+    float* bias_slabs = g.slabs + total_tiles * g.splits * (size_t)(BMK * BN) + ((size_t)((unsigned)bp * g.tiles_y + bid_y) * g.splits) * BN;
+    if (do_bias && tid < CPRB) {
+      const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias_slabs + (size_t)zsplit * BN, BN * 4u);
+      buf_store4_sc1(rb, (unsigned)tid * 16u, bias_t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    volatile int* flag = reinterpret_cast<volatile int*>(lds);
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(g.splits - 1);
+      if (last) __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0] == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // compiler-only: keeps the slab loads below the ticket
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int kGroup = (TM * TN == 1) ? 4 : 1;      // slabs in flight per round trip, bounded by the register budget of the K loop
+    for (int s0 = 0; s0 < g.splits; s0 += kGroup) {
+      float4 v[kGroup][TM * TN * 4];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g.slabs + ((size_t)tile * g.splits + (s0 + u < g.splits ? s0 + u : 0)) * (BMK * BN), BMK * BN * 4u);
+        const unsigned off = (s0 + u < g.splits) ? lane_off : kOOB;
+#pragma unroll
+        for (int t = 0; t < TM * TN * 4; ++t) v[u][t] = buf_load4_sc1(rsrc, off + (unsigned)(((t >> 2) * 64 * 16 + (t & 3) * 4) * 4));
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 w = v[u][(i * TN + j) * 4 + q];
+              acc[i][j][4 * q] += w.x; acc[i][j][4 * q + 1] += w.y; acc[i][j][4 * q + 2] += w.z; acc[i][j][4 * q + 3] += w.w;
+            }
+    }
+    if (do_bias && tid < CPRB) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < g.splits; ++z) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias_slabs + (size_t)z * BN, BN * 4u);
+        const float4 u = buf_load4_sc1(rb, (unsigned)tid * 16u);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      const int n = n0 + tid * 4;
+      if (n < g.N) {           // this workgroup is the only writer of db[n0 .. n0+BN) in the launch
+        g.db[n] += t.x; g.db[n + 1] += t.y; g.db[n + 2] += t.z; g.db[n + 3] += t.w;
       }
     }
   }
@@ -952,7 +1039,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __res
         const int k = k0 + wm * (BMK / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (n < g.N && k < g.K) {
           float* p = g.dw + bp * g.dw_bstride + (size_t)k * g.ldw + n;
-          if (g.atomic) atomicAdd(p, acc[i][j][r]);
+          if (ordered) *p = g.accumulate ? *p + acc[i][j][r] : acc[i][j][r];
+          else if (g.atomic) atomicAdd(p, acc[i][j][r]);
           else *p = acc[i][j][r];
         }
       }
@@ -1151,6 +1239,7 @@ struct PairCapture {
   unsigned ax = 0, ay = 0;
   WgradArgs gw;
   unsigned wx = 0, wy = 0, wz = 0;
+  uint64_t a_slab_bytes = 0, w_slab_bytes = 0;      // split-K slabs at the start / ordered wgrad slabs at the end of the workspace
   double flops = 0.0;
 };
 struct PairPause {
@@ -1216,6 +1305,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       pc->have_a = true;
       pc->a_ok = bmode == 1 && !smallc && t.bm == 64 && t.bn == 64 && t.waves != 8 && g.batch <= 1;
       pc->ga = g;
+      pc->a_slab_bytes = tb ? (uint64_t)tb->n_slots * t.bm * t.bn * sizeof(float) : 0;
       pc->ax = g.units != nullptr ? (unsigned)n_units : (unsigned)radnet_cdiv(g.M, t.bm);
       pc->ay = g.units != nullptr ? 1u : (unsigned)radnet_cdiv(g.N, t.bn);
       pc->flops += 2.0 * g.M * g.N * g.K;
@@ -1287,10 +1377,15 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   }
   radnet_timing_arm(ctx);
   int rc = launch(tc);
-  if (rc == RADNET_ERR_UNSUPPORTED && ctx->force_a <= 0) {      // a shared / loaded choice whose slabs exceed THIS context's workspace
-    tc.splits = tc.splits < 0 ? -1 : 1;
+  if (rc == RADNET_ERR_UNSUPPORTED && ctx->force_a <= 0) {
+    // a shared / loaded / adopted choice this launch cannot use: slabs larger than THIS context's workspace, or a K-split /
+    // XCD-ordered unit table for a problem that is now launched as a batch (a batch is one plain grid per problem)
+    tc.splits = g.batch > 1 ? 1 : (tc.splits < 0 ? -1 : 1);
     rc = launch(tc);
   }
+  if (rc == RADNET_ERR_UNSUPPORTED)
+    RADNET_FAIL(ctx, rc, "conv: launch shape tile %dx%d slices %d waves %d cannot run M=%d N=%d K=%d batch=%d (workspace %llu bytes)", tc.bm, tc.bn,
+                tc.splits, tc.waves, g.M, g.N, g.K, g.batch, (unsigned long long)ctx->ws_bytes);
   if (rc != RADNET_OK) return rc;
   radnet_timing_end_armed(ctx, cls, 2.0 * g.M * g.N * g.K * (g.batch > 1 ? g.batch : 1));
   return RADNET_OK;
@@ -1384,20 +1479,37 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   }
   if (d->c % 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
   const int nmt = radnet_cdiv(g.M, BK);
+  uint64_t wgrad_slab_bytes = 0;
   auto launch = [&](int bmk, int bn, int splits) -> int {
+    wgrad_slab_bytes = 0;
     g.mt_per_split = radnet_cdiv(nmt, splits);
     g.splits = splits;
     // dw_accumulate: 0 = overwrite, 1 = add to existing contents, 2 = destination is pre-zeroed by the caller
     // (plain stores when un-split, atomics without the memset when split)
     g.atomic = (splits > 1 || d->dw_accumulate == 1) ? 1 : 0;
-    if (splits > 1 && d->dw_accumulate == 0)  // atomics need a zeroed destination
-      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (batch > 1 ? (size_t)batch * dw_bs : (size_t)g.K * g.ldw) * sizeof(float), ctx->stream));
     dim3 grid(radnet_cdiv(g.K, bmk), radnet_cdiv(g.N, bn), splits * (batch > 1 ? batch : 1)), block(NTHREADS);
+    g.slabs = nullptr;
+    g.counters = nullptr;
+    g.tiles_x = (int)grid.x; g.tiles_y = (int)grid.y;
+    g.accumulate = d->dw_accumulate == 1;
+    if (splits > 1 && ctx->deterministic) {
+      // ordered reduction: slabs at the END of the workspace (a dgrad launch paired with this one keeps its split-K slabs at the start)
+      const uint64_t tiles = (uint64_t)grid.x * grid.y * (batch > 1 ? batch : 1);
+      const uint64_t need = (tiles * splits * (uint64_t)(bmk * bn) + (uint64_t)grid.y * (batch > 1 ? batch : 1) * splits * bn) * sizeof(float);
+      if (tiles > kAuxWgradCounterCount || ctx->ws == nullptr || need > ctx->ws_bytes) return RADNET_ERR_UNSUPPORTED;      // candidate skipped
+      g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->ws) + ((ctx->ws_bytes - need) & ~(uint64_t)255));
+      g.counters = reinterpret_cast<unsigned*>(ctx->aux + kAuxWgradCounters);
+      g.atomic = 0;
+      wgrad_slab_bytes = need + 256;
+    } else if (splits > 1 && d->dw_accumulate == 0) {  // atomics need a zeroed destination
+      RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->dw, 0, (batch > 1 ? (size_t)batch * dw_bs : (size_t)g.K * g.ldw) * sizeof(float), ctx->stream));
+    }
     if (ctx->pair_capture != nullptr) {
       PairCapture* pc = (PairCapture*)ctx->pair_capture;
       pc->have_w = true;
       pc->w_ok = bmk == 64 && bn == 64 && batch <= 1;
       pc->gw = g;
+      pc->w_slab_bytes = wgrad_slab_bytes;
       pc->wx = grid.x; pc->wy = grid.y; pc->wz = grid.z;
       pc->flops += 2.0 * g.M * g.N * g.K;
       return RADNET_OK;
@@ -1433,6 +1545,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
           if (s > 1 && (nmt / s < 2 || radnet_cdiv(nmt, radnet_cdiv(nmt, s)) != s)) continue;
           float ms = 0.f;
           int rc = radnet_time_launches(ctx, [&]() { return launch(cb, cn, s); }, 3, &ms);
+          if (rc == RADNET_ERR_UNSUPPORTED) continue;      // ordered reduction: slabs larger than the workspace
           if (rc != RADNET_OK) return rc;
           seen.push_back(WCand{ms, cb, cn, s});
         }
@@ -1475,6 +1588,14 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     g.db = d->db;
     if (d->db && d->dw_accumulate == 0) RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->db, 0, (size_t)g.N * sizeof(float), ctx->stream));
     int rc = launch(bmk, bn, splits);
+    if (rc == RADNET_ERR_UNSUPPORTED && splits > 1) {      // a forced / shared / loaded choice whose slabs exceed THIS context's workspace
+      while (rc == RADNET_ERR_UNSUPPORTED && splits > 1) {
+        splits = splits > 2 ? splits / 2 : 1;
+        while (splits > 1 && radnet_cdiv(nmt, radnet_cdiv(nmt, splits)) != splits) --splits;      // no empty split
+        rc = launch(bmk, bn, splits);
+      }
+    }
+    if (rc == RADNET_ERR_UNSUPPORTED) RADNET_FAIL(ctx, rc, "conv_wgrad: no launch shape fits (tile %dx%d, workspace %llu bytes)", bmk, bn, (unsigned long long)ctx->ws_bytes);
     if (rc != RADNET_OK) return rc;
   }
   RADNET_CHECK_LAUNCH(ctx, "conv_wgrad");
@@ -1503,6 +1624,7 @@ extern "C" int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   ctx->pair_capture = nullptr;
   ctx->timing = timed;
   if (rc != RADNET_OK) return rc;
+  if (pc.a_slab_bytes + pc.w_slab_bytes > ctx->ws_bytes) pc.a_ok = false;      // the two problems' slabs would overlap in the workspace
   if (!(pc.have_a && pc.have_w && pc.a_ok && pc.w_ok)) {      // not the fusable shapes: issue them one after the other
     rc = radnet_conv_wgrad(ctx, d);
     return rc != RADNET_OK ? rc : radnet_conv_dgrad(ctx, d);

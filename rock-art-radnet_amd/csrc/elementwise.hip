@@ -111,6 +111,52 @@ __global__ void __launch_bounds__(256) roi_resize_bwd_kernel(const float* __rest
   }
 }
 
+// Ordered form of the same gradient (radnet_ctx::deterministic): overlapping RoIs add into the same feature-map pixel, and
+// the atomics above add them in whatever order the workgroups run.  Here a workgroup (one wave) OWNS one feature-map row and
+// 64 channels: it walks the RoIs, their output rows and output columns in index order, adds the taps that land in its row
+// into an LDS copy of the row (lane = channel, so every address has one writer with one program order) and adds the copy
+// to dfmap once at the end.
+__global__ void __launch_bounds__(64) roi_resize_bwd_ordered_kernel(const float* __restrict__ dy, int H, int W, int C,
+                                                                    const float* __restrict__ rois, int R, int ps, float* __restrict__ dfmap) {
+  extern __shared__ float row[];                // [W][64]
+  const int y = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
+  const bool live = c < C;
+  for (int x = 0; x < W; ++x) row[x * 64 + threadIdx.x] = 0.f;
+  bool touched = false;
+  for (int r = 0; r < R; ++r) {
+    const RoiGeom g = roi_geom(rois + 4 * r, H, W);
+    if (g.cw <= 0 || g.ch <= 0 || y < g.y0 || y >= g.y0 + g.ch) continue;      // uniform for the workgroup
+    const float hs = (float)g.ch / (float)ps, ws = (float)g.cw / (float)ps;
+    for (int oy = 0; oy < ps; ++oy) {
+      const float sy = (float)oy * hs;
+      const int ylo = (int)floorf(sy), yhi = min(ylo + 1, g.ch - 1);
+      const float ly = sy - (float)ylo;
+      const bool top = g.y0 + ylo == y, bot = g.y0 + yhi == y;
+      if (!top && !bot) continue;
+      touched = true;
+      for (int ox = 0; ox < ps; ++ox) {
+        const float sx = (float)ox * ws;
+        const int xlo = (int)floorf(sx), xhi = min(xlo + 1, g.cw - 1);
+        const float lx = sx - (float)xlo;
+        const float v = live ? dy[((long long)(r * ps + oy) * ps + ox) * C + c] : 0.f;
+        float* lo = row + (g.x0 + xlo) * 64 + threadIdx.x;
+        float* hi = row + (g.x0 + xhi) * 64 + threadIdx.x;
+        if (top) {
+          *lo += v * (1.f - ly) * (1.f - lx);
+          *hi += v * (1.f - ly) * lx;
+        }
+        if (bot) {
+          *lo += v * ly * (1.f - lx);
+          *hi += v * ly * lx;
+        }
+      }
+    }
+  }
+  if (!touched || !live) return;
+  float* dst = dfmap + (long long)y * W * C + c;
+  for (int x = 0; x < W; ++x) dst[(long long)x * C] += row[x * 64 + threadIdx.x];
+}
+
 // ---- AveragePooling2D((7,7)) + Flatten over the RoI axis (resnet50.py:260-261) ----------------------
 __global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, int r, int hw, int c4, float* __restrict__ y) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,9 +270,14 @@ __global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __res
 }
 
 // ---- column sums (bias gradients) ----------------------------------------------------------------------
+// `partials` != null (radnet_ctx::deterministic): the row blocks of a column block hand their partial sums to the last one
+// to arrive, which adds them in row-block order (sc1 stores / relaxed agent-scope ticket / sc1 loads, as the split-K
+// reduction of conv_mfma.hip) -- the same bits on every run.  partials == null: one fp32 atomic per block and column.
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int m, int n, int ld, const float* __restrict__ gscale,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block, float* __restrict__ partials,
+                                                     unsigned* __restrict__ counters) {
   __shared__ float red[4][64];
+  __shared__ int s_last;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + tx;
   const int r0 = blockIdx.y * rows_per_block;
@@ -236,11 +287,29 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
     for (int rr = r0 + ty; rr < r1; rr += 4) s += g[(long long)rr * ld + col];
   red[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && col < n) {
-    float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-    if (gscale) v *= gscale[col];
-    atomicAdd(out + col, v);
+  float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+  if (partials == nullptr) {
+    if (ty == 0 && col < n) {
+      if (gscale) v *= gscale[col];
+      atomicAdd(out + col, v);
+    }
+    return;
   }
+  if (ty == 0) __hip_atomic_store(partials + (size_t)blockIdx.y * kAuxColsumCols + blockIdx.x * 64 + tx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.y - 1;
+    if (s_last) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last || ty != 0 || col >= n) return;
+  float t = 0.f;
+  for (unsigned b = 0; b < gridDim.y; ++b)
+    t += __hip_atomic_load(partials + (size_t)b * kAuxColsumCols + blockIdx.x * 64 + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gscale) t *= gscale[col];
+  out[col] += t;                   // this workgroup is the only writer of its 64 columns in the launch
 }
 
 // ---- keras.optimizers.Adam (Keras 2 update rule) over a flat arena ------------------------------------------
@@ -277,7 +346,7 @@ __device__ __forceinline__ float bce_swapped_logit(float t) {
 
 __global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,
                                                             const float* __restrict__ yregr, int m, int a, int bce_mode,
-                                                            double* __restrict__ scratch) {
+                                                            double* __restrict__ scratch, double* __restrict__ partials) {
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   const long long total = (long long)m * 5 * a;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -311,7 +380,28 @@ __global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; }
   __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(scratch + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (partials == nullptr) {
+    if (threadIdx.x < 4) atomicAdd(scratch + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    return;
+  }
+  // ordered form: the blocks' sums are added in block order by the last block to arrive (scratch[4] holds the arrival
+  // counter, zeroed with the rest of scratch by the launcher's memset)
+  __shared__ int s_last;
+  if (threadIdx.x < 4)
+    __hip_atomic_store(partials + 4 * blockIdx.x + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(scratch + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 4) {
+    double t = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) t += __hip_atomic_load(partials + 4 * b + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scratch[threadIdx.x] = t;
+  }
 }
 
 __global__ void __launch_bounds__(256) rpn_loss_grad_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,
@@ -484,7 +574,11 @@ extern "C" int radnet_roi_resize_fwd(radnet_ctx* ctx, const float* fmap, int32_t
 extern "C" int radnet_roi_resize_bwd(radnet_ctx* ctx, const float* dy, int32_t h, int32_t w, int32_t c, const float* rois, int32_t r,
                                      int32_t ps, float* dfmap) {
   if (!ctx || !dy || !rois || !dfmap) return RADNET_ERR_ARG;
-  hipLaunchKernelGGL(roi_resize_bwd_kernel, dim3(r * ps * ps), dim3(256), 0, ctx->stream, dy, h, w, c, rois, ps, dfmap);
+  const size_t smem = (size_t)w * 64 * sizeof(float);
+  if (ctx->deterministic && smem <= 64 * 1024)
+    hipLaunchKernelGGL(roi_resize_bwd_ordered_kernel, dim3(h, radnet_cdiv(c, 64)), dim3(64), smem, ctx->stream, dy, h, w, c, rois, r, ps, dfmap);
+  else
+    hipLaunchKernelGGL(roi_resize_bwd_kernel, dim3(r * ps * ps), dim3(256), 0, ctx->stream, dy, h, w, c, rois, ps, dfmap);
   RADNET_CHECK_LAUNCH(ctx, "roi_resize_bwd");
   return RADNET_OK;
 }
@@ -531,9 +625,15 @@ extern "C" int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t
                              int32_t accumulate) {
   if (!ctx || !g || !out) return RADNET_ERR_ARG;
   if (!accumulate) RADNET_CHECK_HIP(ctx, hipMemsetAsync(out, 0, (size_t)n * sizeof(float), ctx->stream));
-  const int rows_per_block = 128;
+  int rows_per_block = 128;
+  float* partials = nullptr;
+  if (ctx->deterministic && m > rows_per_block) {
+    if (n > (int)kAuxColsumCols || radnet_cdiv(n, 64) > (int)kAuxColsumCounterCount) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "colsum: n=%d", n);
+    while (radnet_cdiv(m, rows_per_block) > (int)kAuxColsumRows) rows_per_block *= 2;
+    partials = reinterpret_cast<float*>(ctx->aux + kAuxColsumScratch);
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(radnet_cdiv(n, 64), radnet_cdiv(m, rows_per_block)), dim3(256), 0, ctx->stream, g, m, n, ld, gscale,
-                     out, rows_per_block);
+                     out, rows_per_block, partials, reinterpret_cast<unsigned*>(ctx->aux + kAuxColsumCounters));
   RADNET_CHECK_LAUNCH(ctx, "colsum");
   return RADNET_OK;
 }
@@ -557,7 +657,7 @@ extern "C" int radnet_rpn_loss(radnet_ctx* ctx, const float* pred, int32_t ld_pr
   if (ld_pred < 5 * a || ld_dz < 5 * a) RADNET_FAIL(ctx, RADNET_ERR_ARG, "rpn_loss: leading dims too small");
   RADNET_CHECK_HIP(ctx, hipMemsetAsync(scratch8, 0, 8 * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(rpn_loss_sums_kernel, dim3(grid_for((long long)m * 5 * a, 256, 256)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
-                     y_regr, m, a, bce_mode, scratch8);
+                     y_regr, m, a, bce_mode, scratch8, ctx->deterministic ? reinterpret_cast<double*>(ctx->aux + kAuxLossPartials) : nullptr);
   RADNET_CHECK_LAUNCH(ctx, "rpn_loss_sums");
   hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(grid_for((long long)m * ld_dz, 256, 2048)), dim3(256), 0, ctx->stream, pred, ld_pred, y_cls,
                      y_regr, m, a, bce_mode, scratch8, dz, ld_dz, losses);

@@ -184,9 +184,37 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   RADNET_CHECK_HIP(ctx, hipStreamSynchronize(st));
   // host half of the labeller: random subsampling on the caller's RNG (utils.py:785-813)
   const int n_pos = hooks->subsample_anchors(hooks->user, d->h_valid, d->h_overlap, A, d->fh, d->fw);
+  // Data parallel (world > 1): the collectives must stay symmetric.  A rank whose image is dropped, or whose proposals
+  // overlap no box, still joins BOTH exchanges with its (zero) gradient arena and applies the same optimizer steps as its
+  // peers -- otherwise they block in ncclAllReduce for a rank that never comes (radnet_hip/trainer.py does the same).
+  auto head_update = [&]() -> int {
+    int r = RADNET_OK;
+    if (d->world > 1) r = radnet_allreduce_grads(ctx, d->head_opt.g, d->head_opt.n);
+    if (r == RADNET_OK)
+      r = radnet_adam_step(ctx, d->head_opt.p, d->head_opt.g, d->head_opt.m, d->head_opt.v, d->head_opt.n, d->head_opt.t, d->head_opt.lr, 0.9f,
+                           0.999f, 1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
+    if (r == RADNET_OK && d->head_shift) r = radnet_affine_vec(ctx, d->head_shift, d->head_scale, d->head_bias, d->head_t0, d->head_bias_len);
+    return r;
+  };
+  auto rpn_update = [&]() -> int {
+    int r = RADNET_OK;
+    if (d->world > 1) r = radnet_allreduce_grads(ctx, d->rpn_opt.g, d->rpn_opt.n);
+    if (r == RADNET_OK)
+      r = radnet_adam_step(ctx, d->rpn_opt.p, d->rpn_opt.g, d->rpn_opt.m, d->rpn_opt.v, d->rpn_opt.n, d->rpn_opt.t, d->rpn_opt.lr, 0.9f, 0.999f,
+                           1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
+    if (r == RADNET_OK && d->wino_w)
+      r = d->wino_form == 4 ? radnet_winograd4_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u)
+                            : radnet_winograd_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u);
+    return r;
+  };
   if (n_pos < 0) {                          // labeller failure: the reference's generator skips the sample (utils.py:461-465)
     *took_head_step = -1;
-    return RADNET_OK;
+    if (d->world > 1) {                     // nothing of this image touched a gradient: both arenas hold zeros
+      rc = rpn_update();
+      if (rc == RADNET_OK) rc = head_update();
+      if (rc == RADNET_OK) RADNET_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return rc;
   }
   RADNET_CHECK_HIP(ctx, hipMemcpyAsync(d->valid, d->h_valid, (size_t)A * M, hipMemcpyHostToDevice, st));
   rc = radnet_anchor_targets_pack(ctx, d->valid, d->overlap, d->regr, d->fw, d->fh, A, d->std_scaling, d->y_cls, d->y_regr);
@@ -194,13 +222,7 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   if (rc == RADNET_OK)
     rc = radnet_rpn_loss(ctx, d->pred, d->ld_pred, d->y_cls, d->y_regr, M, A, d->bce_mode, d->dz, d->ld_pred, d->rpn_losses, d->loss_scratch8);
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, d->rpn_bwd_ops, d->n_rpn_bwd);
-  if (rc == RADNET_OK && d->world > 1) rc = radnet_allreduce_grads(ctx, d->rpn_opt.g, d->rpn_opt.n);
-  if (rc == RADNET_OK)
-    rc = radnet_adam_step(ctx, d->rpn_opt.p, d->rpn_opt.g, d->rpn_opt.m, d->rpn_opt.v, d->rpn_opt.n, d->rpn_opt.t, d->rpn_opt.lr, 0.9f, 0.999f,
-                          1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
-  if (rc == RADNET_OK && d->wino_w)
-    rc = d->wino_form == 4 ? radnet_winograd4_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u)
-                           : radnet_winograd_filter(ctx, d->wino_w, d->wino_c, d->wino_n, d->wino_ldw, d->wino_u);
+  if (rc == RADNET_OK) rc = rpn_update();
   // ---- phase D: re-predict with the updated RPN (train.py:291), proposals, RoI labelling
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, d->rpn_refwd_ops, d->n_rpn_refwd);
   if (rc == RADNET_OK)
@@ -218,7 +240,13 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   const radnet_head_desc& h = *d->head;
   // train.get_selected_samples on the caller's RNG (train.py:93-129); 0 = calc_iou kept nothing, the head step is skipped
   const int k = n > 0 ? hooks->select_rois(hooks->user, d->h_roi_cls, n, d->h_sel, h.n_rois) : 0;
-  if (k <= 0) return RADNET_OK;
+  if (k <= 0) {
+    if (d->world > 1) {                     // the head arena holds zeros: join the peers' exchange and update (see above)
+      rc = head_update();
+      if (rc == RADNET_OK) RADNET_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return rc;
+  }
   if (k != h.n_rois) RADNET_FAIL(ctx, RADNET_ERR_ARG, "train_step: select_rois returned %d indices, the head plan holds %d", k, h.n_rois);
   RADNET_CHECK_HIP(ctx, hipMemcpyAsync(d->sel, d->h_sel, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, st));
   rc = radnet_roi_batch_pack(ctx, d->sel, k, d->roi_cls, d->roi_box, d->roi_t, h.nc, d->bg_class, const_cast<float*>(h.rois), d->y1, d->y2);
@@ -228,12 +256,7 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
     rc = radnet_dense_heads_bwd(ctx, h.feat, d->head_dz, h.n_rois, h.feat_c, h.dense_w, h.dense_ld, h.nc + h.nreg, d->dense_dw, d->dense_db, d->dfeat, 1);
   if (rc == RADNET_OK) rc = radnet_avgpool_bwd_relu(ctx, d->dfeat, h.y5, h.n_rois, h.hw, h.feat_c, d->g_last);
   if (rc == RADNET_OK) rc = radnet_program_run(ctx, d->head_bwd_ops, d->n_head_bwd);
-  if (rc == RADNET_OK && d->world > 1) rc = radnet_allreduce_grads(ctx, d->head_opt.g, d->head_opt.n);
-  if (rc == RADNET_OK)
-    rc = radnet_adam_step(ctx, d->head_opt.p, d->head_opt.g, d->head_opt.m, d->head_opt.v, d->head_opt.n, d->head_opt.t, d->head_opt.lr, 0.9f,
-                          0.999f, 1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
-  if (rc == RADNET_OK && d->head_shift)
-    rc = radnet_affine_vec(ctx, d->head_shift, d->head_scale, d->head_bias, d->head_t0, d->head_bias_len);
+  if (rc == RADNET_OK) rc = head_update();
   if (rc != RADNET_OK) return rc;
   RADNET_CHECK_HIP(ctx, hipMemcpyAsync(losses5 + 2, d->det_losses, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
   RADNET_CHECK_HIP(ctx, hipStreamSynchronize(st));
@@ -329,5 +352,14 @@ extern "C" int radnet_allreduce_grads(radnet_ctx* ctx, float* grads, int64_t cou
   // gradients and before the optimizer step that consumes them, with no host synchronisation
   const int e = r->AllReduce(grads, grads, (size_t)count, 7, 0, ctx->comm, ctx->stream);
   if (e != 0) RADNET_FAIL(ctx, RADNET_ERR_HIP, "ncclAllReduce: %s", r->GetErrorString ? r->GetErrorString(e) : "error");
+  ctx->comm_calls += 1;
+  ctx->comm_elems += count;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_comm_stats(radnet_ctx* ctx, int64_t* calls, int64_t* elements) {
+  if (!ctx) return RADNET_ERR_ARG;
+  if (calls) *calls = ctx->comm_calls;
+  if (elements) *elements = ctx->comm_elems;
   return RADNET_OK;
 }

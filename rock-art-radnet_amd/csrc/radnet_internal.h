@@ -96,7 +96,26 @@ struct radnet_ctx {
   // data-parallel exchange (program.hip): RCCL communicator of this context, bound at run time
   void* comm = nullptr;
   int comm_world = 0;
+  int64_t comm_calls = 0, comm_elems = 0;      // radnet_allreduce_grads issued on this context (radnet_comm_stats)
+  // Ordered (run-to-run reproducible) reductions: arrival counters and partial-sum scratch of the kernels that hand a
+  // reduction to their last-arriving workgroup (split weight gradients, column sums, the RPN loss sums).  One block of
+  // device memory per context (radnet_create), zeroed once; every launch leaves its counters at zero again.
+  // deterministic = 1 (default; RADNET_DETERMINISTIC=0 turns it off): no floating-point atomics anywhere in a training step.
+  int deterministic = 1;
+  char* aux = nullptr;
 };
+
+// layout of radnet_ctx::aux (bytes)
+constexpr size_t kAuxWgradCounters = 0;                          // 65536 x u32: one per (problem, k tile, n tile) of a split wgrad launch
+constexpr size_t kAuxWgradCounterCount = 65536;
+constexpr size_t kAuxColsumCounters = kAuxWgradCounters + kAuxWgradCounterCount * 4;      // 1024 x u32: one per 64-column block
+constexpr size_t kAuxColsumCounterCount = 1024;
+constexpr size_t kAuxLossPartials = kAuxColsumCounters + kAuxColsumCounterCount * 4;      // 1024 x 4 doubles (rpn_loss_sums blocks)
+constexpr size_t kAuxLossBlocks = 1024;
+constexpr size_t kAuxColsumScratch = kAuxLossPartials + kAuxLossBlocks * 4 * 8;           // kAuxColsumRows x 65536 floats
+constexpr size_t kAuxColsumRows = 32;
+constexpr size_t kAuxColsumCols = 65536;
+constexpr size_t kAuxBytes = kAuxColsumScratch + kAuxColsumRows * kAuxColsumCols * 4;
 
 #define RADNET_FAIL(ctx, code, ...)                         \
   do {                                                      \

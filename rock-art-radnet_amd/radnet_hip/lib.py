@@ -147,6 +147,7 @@ def load_library():
         "radnet_tune_load": (C.c_int, [vp, C.c_char_p]),
         "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "radnet_force_waves": (C.c_int, [vp, C.c_int]),
+        "radnet_set_deterministic": (C.c_int, [vp, C.c_int]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
         "radnet_timing_reset": (C.c_int, [vp]),
@@ -205,6 +206,7 @@ def load_library():
         "radnet_comm_init": (C.c_int, [vp, i32, i32, C.c_char_p]),
         "radnet_comm_destroy": (C.c_int, [vp]),
         "radnet_allreduce_grads": (C.c_int, [vp, vp, i64]),
+        "radnet_comm_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
     }
     for name, (res, args) in sig.items():

@@ -79,7 +79,12 @@ class NativeTrainStep:
         self._last = None
         bg, n_rois = int(eng.bg), int(eng.C.n_rois)
 
+        self.force_drop = False        # tests: the labeller hook reports a failure / the RoI hook keeps nothing
+        self.force_no_rois = False
+
         def subsample(user, valid_p, overlap_p, a, fh, fw):
+            if self.force_drop:
+                return -1
             valid = np.ctypeslib.as_array(valid_p, shape=(a, fh, fw))
             overlap = np.ctypeslib.as_array(overlap_p, shape=(a, fh, fw))
             try:
@@ -88,6 +93,8 @@ class NativeTrainStep:
                 return -1
 
         def select(user, cls_p, n, sel_p, k):
+            if self.force_no_rois:
+                return 0
             cls = np.ctypeslib.as_array(cls_p, shape=(n,))
             kept = np.nonzero(cls >= 0)[0]
             if len(kept) == 0:
@@ -195,14 +202,17 @@ class NativeTrainStep:
         took = C.c_int32(0)
         n_drop = self.dropped_images
         eng.ctx.check(eng.lib.radnet_train_step(eng.ctx.h, C.byref(d), C.byref(self.hooks), losses, C.byref(took)), "radnet_train_step")
-        if took.value < 0:                       # dropped by the labeller hook: nothing was trained
+        if took.value < 0:                       # dropped by the labeller hook: nothing of this image was trained on
             self.dropped_images += 1
-        else:
+        elif not took.value:
+            self.skipped_head_steps += 1
+        # world > 1: the rank joined both exchanges and applied both optimizer steps whatever its own image did (program.hip)
+        if took.value >= 0 or self.world > 1:
             eng.rpn_arena.t += 1
-            if took.value:
-                eng.head_arena.t += 1
-            else:
-                self.skipped_head_steps += 1
+        if took.value > 0 or self.world > 1:
+            eng.head_arena.t += 1
+            # the inference head plans keep Winograd-transformed copies of the classifier's 3x3 filters (sync_inference_filters)
+            eng._inference_filters_stale = True
         self._last = dict(rpn_cls=float(losses[0]), rpn_regr=float(losses[1]), det_cls=float(losses[2]), det_regr=float(losses[3]),
                           det_acc=float(losses[4]), n_head=max(int(took.value), 0), dropped=self.dropped_images - n_drop)
         if self.capture is not None and self.capture:

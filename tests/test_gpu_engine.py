@@ -268,7 +268,7 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead, sta
     """The pipelined step (TrainStep.step(batch, upcoming=[...]): prefetch lanes for the announced batches' base forward, the
     next batch's RPN phase ahead of this batch's head phase, head phase on its own lane -- what bench.py runs) against
     back-to-back steps on one lane.  Same arithmetic, same order of NumPy RNG draws: losses, weights and RNG consumption
-    must agree (up to the fp32 atomics of split wgrad launches).  (7, 3): more batches than buffer sets, full lookahead."""
+    agree BIT FOR BIT (ordered reductions).  (7, 3): more batches than buffer sets, full lookahead."""
     from faster_rcnn.config import Config
     from oracle import dense
     from radnet_hip import synth
@@ -320,33 +320,26 @@ def test_prefetched_next_batch_equals_back_to_back_steps(n_steps, lookahead, sta
             return None
         if r0 != r1:
             return ("consumption of the global NumPy stream", r0, r1)
-        # wgrad sums its K slices with fp32 atomics (order varies from run to run) and Adam turns a last-bit difference of a tiny
-        # gradient into a visible fraction of lr = 5e-5, so the two runs drift apart like any two runs of the same schedule do:
-        # the first steps must agree to 1e-5, the later ones to 1e-3 -- a scheduling bug (a stale buffer set, a phase reading
-        # weights of the wrong step) shows as an O(1) difference, at the step where a buffer set is reused at the latest
+        # Every reduction of the step is ordered (radnet_set_deterministic, on by default: split weight gradients, bias column
+        # sums and loss sums are added in index order by one workgroup) and both runs use one table of launch shapes, so the two
+        # schedules execute the same arithmetic on the same operands: EVERY loss of every step and EVERY weight must agree
+        # bit for bit.  Any difference is a scheduling bug (a missing event dependency between lanes, a buffer set reused while a
+        # lane still reads it), however small it looks.
         for i, (a, b) in enumerate(zip(l0, l1)):
             if not a["n_head"] == b["n_head"] == 1:
                 return ("n_head", i, a, b)
-            tol = 1e-5 if i < 4 else 1e-3
             for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
-                if not abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])):
+                if a[k] != b[k]:
                     return ("loss", i, k, a[k], b[k])
-        # almost every weight agrees to the last bits, none moves by more than a fraction of lr per step taken
-        for name in ("rpn_conv1", "rpn_out_class", "res5a_branch2a", "res5c_branch2c", "dense_class_7"):
-            for k in ("kernel", "bias"):
-                d = np.abs(w0[name][k] - w1[name][k])
-                if not (d.max() < 2e-6 * max(n_steps, 3) and np.mean(d < 3e-7) > 0.995):
-                    return ("weights", name, k, float(d.max()), float(np.mean(d < 3e-7)))
+        for name in w0:
+            for k in w0[name]:
+                if not np.array_equal(w0[name][k], w1[name][k]):
+                    d = np.abs(w0[name][k] - w1[name][k])
+                    return ("weights", name, k, float(d.max()), float(np.mean(d > 0)))
         return None
 
     seq = run(False)
     diff = compare(seq, run(True))
-    if diff is not None:
-        # Two runs of even the SAME schedule can part ways for good when an atomics-order rounding difference flips a near-tie
-        # (a ReLU at zero, two proposals of equal score): rare (about one comparison in fifteen on this suite's inputs), and a
-        # scheduling bug is not rare -- it repeats.  One repetition of the pipelined leg decides.
-        print("first comparison differed:", diff)
-        diff = compare(seq, run(True))
     assert diff is None, diff
 
 
@@ -423,19 +416,16 @@ def test_run_training_from_tile_feed():
         (w0, r0, s0), (w1, r1, s1) = a, b
         if not (r0 == r1 and s0 == s1):
             return ("random stream / skipped heads", r0, r1, s0, s1)
-        # wgrad sums its K slices with fp32 atomics (order varies from run to run) and Adam turns a last-bit difference of a tiny
-        # gradient into a visible fraction of lr = 5e-5: almost every weight agrees to the last bits, none moves by more than lr / 5
-        for name in ("rpn_conv1", "res5a_branch2a", "dense_class_7"):
-            d = np.abs(w0[name]["kernel"] - w1[name]["kernel"])
-            if not (d.max() < 1e-5 and np.mean(d < 3e-7) > 0.995):
-                return (name, float(d.max()), float(np.mean(d < 3e-7)))
+        # ordered reductions + one table of launch shapes: the two schedules must agree bit for bit
+        for name in w0:
+            for k in w0[name]:
+                if not np.array_equal(w0[name][k], w1[name][k]):
+                    d = np.abs(w0[name][k] - w1[name][k])
+                    return (name, k, float(d.max()), float(np.mean(d > 0)))
         return None
 
     one = run(0)
     diff = compare(one, run(3))
-    if diff is not None:          # atomics-order drift can flip a near-tie for good (rare); a scheduling bug repeats: one repetition decides
-        print("first comparison differed:", diff)
-        diff = compare(one, run(3))
     assert diff is None, diff
 
 

@@ -143,9 +143,10 @@ def test_full_size_pipelined_equals_back_to_back(full_step):
             eng.save_tuning(tune)
     (l0, w0, r0, s0), (l1, w1, r1, s1) = res
     assert r0 == r1 and s0 == s1 == 0
-    for a, b in zip(l0, l1):
-        for key in ("rpn_cls", "rpn_regr", "det_cls", "det_regr"):
-            assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(a[key])), key
-    for name in ("rpn_conv1", "res5a_branch2a", "res5c_branch2c"):
-        d = np.abs(w0[name]["kernel"] - w1[name]["kernel"])
-        assert d.max() < 5e-6 and np.mean(d < 3e-7) > 0.999, (name, float(d.max()))
+    # ordered reductions (radnet_set_deterministic, default) + one table of launch shapes: bit for bit, every loss, every weight
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        for key in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
+            assert a[key] == b[key], (i, key, a[key], b[key])
+    for name in w0:
+        for k in w0[name]:
+            assert np.array_equal(w0[name][k], w1[name][k]), (name, k, float(np.abs(w0[name][k] - w1[name][k]).max()))

@@ -102,10 +102,78 @@ def test_train_step_composed_equals_scheduler_one_lane():
         assert a["n_head"] == b["n_head"] == 1
         assert ca["sel_kept"] == cb["sel_kept"] and np.array_equal(ca["R"], cb["R"])
         for k in ("rpn_cls", "rpn_regr", "det_cls", "det_regr", "det_acc"):
-            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+            assert a[k] == b[k], (k, a[k], b[k])
     for name in wa:
         for k in wa[name]:
-            assert np.allclose(wa[name][k], wb[name][k], rtol=0, atol=2e-7), (name, k)     # split wgrad sums with fp32 atomics
+            assert np.array_equal(wa[name][k], wb[name][k]), (name, k)     # ordered reductions: the native step is the same arithmetic
+
+
+def _comm_stats(eng):
+    import ctypes as C
+    calls, elems = C.c_int64(0), C.c_int64(0)
+    eng.ctx.check(eng.lib.radnet_comm_stats(eng.ctx.h, C.byref(calls), C.byref(elems)), "comm_stats")
+    return calls.value, elems.value
+
+
+def test_train_step_keeps_the_collectives_symmetric_on_its_early_exits():
+    """Data parallel (world > 1): a rank whose image the labeller drops (n_pos < 0), or whose RoI hook keeps nothing, must
+    still issue the SAME sequence of gradient exchanges as a peer that trains on its image -- RPN arena, then head arena --
+    or the peers block in ncclAllReduce.  Rehearsed on one GPU: the descriptor says world = 2, the communicator has
+    one rank, radnet_comm_stats counts the exchanges per path; zero gradients leave first-step weights where they were."""
+    from radnet_hip import native
+    C, P, eng = make()
+    native.comm_init(eng, 1, 0)
+    n_rpn, n_head = eng.rpn_arena.n, eng.head_arena.n
+    try:
+        nt = native.NativeTrainStep(eng, world=2)
+        w0 = eng.get_weights()
+        # (1) labeller failure
+        nt.force_drop = True
+        c0, e0 = _comm_stats(eng)
+        nt.step(sample(0))
+        c1, e1 = _comm_stats(eng)
+        assert nt.losses()["dropped"] == 1 and nt.losses()["n_head"] == 0
+        assert (c1 - c0, e1 - e0) == (2, n_rpn + n_head)
+        assert eng.rpn_arena.t == 1 and eng.head_arena.t == 1                  # the peers' step counters
+        w1 = eng.get_weights()
+        for name in w0:
+            for k in w0[name]:
+                assert np.array_equal(w0[name][k], w1[name][k]), (name, k)      # Adam on zeros with zero moments: no move
+        # (2) no RoI kept: the RPN phase trains, the head joins with zeros
+        nt.force_drop, nt.force_no_rois = False, True
+        np.random.seed(64)
+        nt.step(sample(1))
+        c2, e2 = _comm_stats(eng)
+        assert (c2 - c1, e2 - e1) == (2, n_rpn + n_head)
+        assert nt.losses()["n_head"] == 0 and nt.skipped_head_steps == 1
+        assert eng.rpn_arena.t == 2 and eng.head_arena.t == 2
+        w2 = eng.get_weights()
+        assert not np.array_equal(w1["rpn_conv1"]["kernel"], w2["rpn_conv1"]["kernel"])
+        assert np.array_equal(w1["res5a_branch2a"]["kernel"], w2["res5a_branch2a"]["kernel"])
+        # (3) a full step: the same two exchanges
+        nt.force_no_rois = False
+        nt.step(sample(2))
+        c3, e3 = _comm_stats(eng)
+        assert (c3 - c2, e3 - e2) == (2, n_rpn + n_head) and nt.losses()["n_head"] == 1
+        # world = 1 takes no part in any exchange
+        nt1 = native.NativeTrainStep(eng, world=1)
+        nt1.force_drop = True
+        nt1.step(sample(3))
+        assert _comm_stats(eng) == (c3, e3)
+    finally:
+        eng.ctx.check(eng.lib.radnet_comm_destroy(eng.ctx.h), "comm_destroy")
+
+
+def test_native_step_marks_inference_filters_stale():
+    """After radnet_train_step moved the head weights, an inference head plan (Winograd-transformed copies of the classifier's
+    3x3 filters) must re-transform them before its next pass."""
+    from radnet_hip import native
+    C, P, eng = make()
+    eng._inference_filters_stale = False
+    np.random.seed(64)
+    nt = native.NativeTrainStep(eng)
+    nt.step(sample(0))
+    assert nt.losses()["n_head"] == 1 and eng._inference_filters_stale is True
 
 
 def test_allreduce_grads_one_rank_communicator():
