@@ -130,6 +130,8 @@ def roi_crop_resize_bwd(fmap_shape, rois, ps, dout):
         y0, y1 = min(max(y, 0), H), min(max(y + h, 0), H)
         x0, x1 = min(max(x, 0), W), min(max(x + w, 0), W)
         ch, cw = y1 - y0, x1 - x0
+        if ch <= 0 or cw <= 0:          # empty crop: the forward pass produced zeros that depend on nothing
+            continue
         hs = f32(ch) / f32(ps); ws = f32(cw) / f32(ps)
         for oy in range(ps):
             sy = f32(oy) * hs

@@ -61,13 +61,20 @@ def test_tile_feed_matches_reference_generator(case):
     C = Config()
     C.img_size, C.tile_size, C.tile_overlap = 300, 300, 150
     C.max_n_tiles_train, C.max_n_tiles_val = 2, 3
-    C.balanced_classes, C.include_full_img, C.use_img_type = case["balanced"], False, False
+    C.balanced_classes, C.include_full_img, C.use_img_type = case["balanced"], bool(case.get("full", False)), False
     for k in AUG:
         setattr(C, k, False)
     data, imgs = dataset(case["data_seed"], [tuple(s) for s in case["sizes"]])
     class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in CLASSES}
     np.random.seed(case["seed"])
-    feed = iter(F.TileFeed(data, C, class_count, lambda d, t: imgs[d["filepath"]], train_mode=case["train"]))
+    # *_full cases (C.include_full_img, utils.py:484-549): the whole image follows its tiles, scaled to the network size.  The
+    # reference ran with cv2.resize bound to oracle/resize.py (tools/gen_golden.py); the feed gets the same function as its
+    # resize hook here (the device kernel that is its default is bit-identical to it: tests/test_gpu_resize.py, and
+    # tests/test_gpu_radnet.py::test_tile_feed_full_image_pass_device_resize runs these cases through it)
+    from oracle import resize as oresize
+    feed = iter(F.TileFeed(data, C, class_count, lambda d, t: imgs[d["filepath"]], train_mode=case["train"],
+                           resize=(lambda im, w, h: oresize.resize_bicubic_u8(np.ascontiguousarray(im), w, h)) if case.get("full") else None))
+    n_full = 0
     got = 0
     for ref in case["yields"]:
         s = next(feed)
@@ -81,6 +88,10 @@ def test_tile_feed_matches_reference_generator(case):
         n_pos = glue.anchor_targets(C, boxes, is_bg, s["width"], s["height"], rw, rh, lambda w, h: (glue.resnet50_feat_len(w), glue.resnet50_feat_len(h)))[3]
         assert int(n_pos) == ref["n_pos"]
         got += 1
+        if (s["width"], s["height"]) != (300, 300):
+            n_full += 1
+            assert s["img"].shape[:2] == (rh, rw) and min(rw, rh) == 300          # the sample carries the RESIZED panel
+    assert (n_full > 0) == bool(case.get("full", False))
     if not case["train"]:
         with pytest.raises(StopIteration):          # one pass in validation mode (the reference ends it with an exception)
             next(feed)

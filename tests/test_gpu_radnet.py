@@ -105,6 +105,64 @@ def test_radnet_predict_matches_reference_output():
     assert got == ref
 
 
+def _same_detections(dets, g, prefix):
+    assert len(dets) == int(g[prefix + "n"])
+    got = sorted((d["class"], int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"]), float(d["prob"])) for d in dets)
+    ref = sorted((str(c), int(b[0]), int(b[1]), int(b[2]), int(b[3]), float(p)) for c, b, p in zip(g[prefix + "classes"], g[prefix + "boxes"], g[prefix + "probs"]))
+    assert got == ref
+
+
+def test_radnet_predict_full_image_pass_matches_reference_output():
+    """C.include_full_img (RADNet.py:606-665): the whole panel at the network size as one more source of detections.
+    (a) on top of the tiles, panel already at the network size; (b) full image ONLY (max_n_tiles_train = 0), two panels of
+    different sizes scaled by the device bicubic kernel -- the reference ran with cv2.resize bound to oracle/resize.py, which
+    that kernel equals bit for bit -- so format_img's ratio and get_real_coordinates are exercised off the identity."""
+    from faster_rcnn.config import Config
+    from faster_rcnn.RADNet import RADNet
+    g = load_golden("predict_fake")
+    C = Config(); C.tile_size = 600; C.tile_overlap = 300; C.img_size = 600; C.include_full_img = True
+    net = RADNet(C, _FakeRPN(12, 8), _FakeDet(7, 2), lambda x: x - np.float32(100.0))
+    _same_detections(net.predict([g["img"]]), g, "full_")
+    assert int(g["full_n"]) != int(g["n"])                       # the pass changes the result
+    C = Config(); C.img_size = 300; C.include_full_img = True; C.max_n_tiles_train = 0
+    net = RADNet(C, _FakeRPN(12, 4), _FakeDet(7, 6), lambda x: x - np.float32(100.0))
+    _same_detections(net.predict([g["only_img_a"], g["only_img_b"]]), g, "only_")
+
+
+def test_tile_feed_full_image_pass_device_resize():
+    """The *_full cases of tests/golden/tile_feed.json (the reference's generator with C.include_full_img) through TileFeed's
+    DEFAULT resize, the device bicubic kernel: same samples, same pixel sums as the reference's resized panels."""
+    import json
+    import os
+    from faster_rcnn import data_feed as F
+    from faster_rcnn.config import Config
+    from test_data_feed import AUG, CLASSES, dataset
+    from oracle import glue
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tile_feed.json")))
+    cases = [c for c in G["cases"] if c.get("full")]
+    assert len(cases) == 3
+    for case in cases:
+        C = Config()
+        C.img_size, C.tile_size, C.tile_overlap = 300, 300, 150
+        C.max_n_tiles_train, C.max_n_tiles_val = 2, 3
+        C.balanced_classes, C.include_full_img, C.use_img_type = case["balanced"], True, False
+        for k in AUG:
+            setattr(C, k, False)
+        data, imgs = dataset(case["data_seed"], [tuple(s) for s in case["sizes"]])
+        class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in CLASSES}
+        np.random.seed(case["seed"])
+        feed = iter(F.TileFeed(data, C, class_count, lambda d, t: imgs[d["filepath"]], train_mode=case["train"]))
+        for ref in case["yields"]:
+            s = next(feed)
+            assert (s["filepath"], s["width"], s["height"]) == (ref["filepath"], ref["width"], ref["height"])
+            assert int(s["img"].astype(np.int64).sum()) == ref["img_sum"]
+            boxes = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in s["bboxes"]], dtype=np.float64)
+            is_bg = np.array([b["class"] == "bg" for b in s["bboxes"]])
+            rw, rh = glue.new_img_size(s["width"], s["height"], C.img_size)
+            glue.anchor_targets(C, boxes, is_bg, s["width"], s["height"], rw, rh, lambda w, h: (glue.resnet50_feat_len(w), glue.resnet50_feat_len(h)))
+        assert np.random.randint(0, 2 ** 31 - 1) == case["rng_after"]
+
+
 @pytest.fixture(scope="module")
 def models():
     from faster_rcnn import models as M

@@ -86,39 +86,21 @@ def test_borders_replicate(ctx):
     assert (got[0, 20:] == 17).all() and (got[40:, 0] == 200).all()
 
 
-@pytest.mark.parametrize("case", ["identity", "shift", "rot+2.7", "rot-3", "rot31_grow", "shear0.3", "shear0.07", "scale_down", "one_channel"])
-def test_warp_affine_device_equals_numpy_restatement(case):
+from warp_cases import CASES as WARP_CASES, make as warp_case  # noqa: E402
+
+
+@pytest.mark.parametrize("case", WARP_CASES)
+def test_warp_affine_device_equals_oracle(case):
     """radnet_warp_affine_u8 (the rotation / shear warp of the train-time augmentation on the device) against
-    faster_rcnn.augmentation.warp_affine_u8, bit for bit: the matrices augmentation.py builds (centre rotation with the canvas
-    grown and shifted, |f| shear on a widened canvas) and a few others; sources whose warped footprint leaves the destination and
-    destinations that reach outside the source (border 0)."""
+    oracle.imglib.warp_affine_u8 -- the independent per-pixel restatement of OpenCV's 8-bit bilinear warpAffine (10-bit
+    coordinate tables, 1/32-pixel fractions, 15-bit weights, constant border; parity vs cv2 itself unpinned: OpenCV is not
+    importable) -- bit for bit, and against the host form the feed uses without a device."""
     from faster_rcnn import augmentation as A
     from faster_rcnn.RADNet import warp_affine_device
-    rs = np.random.RandomState(len(case))
-    h, w = 157, 203
-    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
-    if case == "identity":
-        m, ds = np.array([[1, 0, 0], [0, 1, 0]], float), (w, h)
-    elif case == "shift":
-        m, ds = np.array([[1, 0, 7.37], [0, 1, -3.21]], float), (w + 9, h + 4)
-    elif case.startswith("rot"):
-        ang = {"rot+2.7": 2.7, "rot-3": -3.0, "rot31_grow": 31.0}[case]
-        m = A.rotation_matrix_2d((w // 2, h // 2), ang, 1.0)
-        c, s = abs(m[0, 0]), abs(m[0, 1])
-        nw, nh = int(h * s + w * c), int(h * c + w * s)
-        m[0, 2] += nw / 2 - w // 2
-        m[1, 2] += nh / 2 - h // 2
-        ds = (nw, nh)
-    elif case.startswith("shear"):
-        f = float(case[5:])
-        m, ds = np.array([[1, f, 0], [0, 1, 0]], float), (int(w + f * h), h)
-    elif case == "scale_down":
-        m, ds = np.array([[0.61, 0.02, 3.3], [-0.04, 0.57, 11.0]], float), (150, 120)
-    else:
-        img = img[:, :, :1].copy()
-        m, ds = A.rotation_matrix_2d((101, 78), 1.3, 1.0), (w, h)
-    ref = A.warp_affine_u8(img, m, ds)
+    from oracle import imglib
+    img, m, ds = warp_case(case)
+    ref = imglib.warp_affine_u8(img, m, ds)
     got = warp_affine_device(img, m, ds)
     assert got.shape == ref.shape and got.dtype == np.uint8
     assert np.array_equal(got, ref), int((got != ref).sum())
-    assert ref.any()
+    assert np.array_equal(A.warp_affine_u8(img, m, ds), ref)

@@ -30,11 +30,17 @@ def _stub_modules():
     cv2.INTER_CUBIC = 2
 
     def _resize(img, size, interpolation=None):
-        # Only identity resizes are exercised by the goldens (tile already at the
-        # target size); anything else would need OpenCV, which is absent.
+        # OpenCV is absent.  Identity resizes (tile already at the target size) copy; the full-image cases
+        # (C.include_full_img: RADNet.py:606-665, utils.py:484-549), where the whole panel is scaled to the
+        # network size, are bound to THIS repo's restatement of cv2's 8-bit INTER_CUBIC (oracle/resize.py,
+        # parity vs cv2 unpinned): what those goldens pin is the reference's code around the resize.
         w, h = size
-        assert img.shape[0] == h and img.shape[1] == w, "stub cv2.resize: identity only"
-        return img.copy()
+        if img.shape[0] == h and img.shape[1] == w:
+            return img.copy()
+        assert interpolation == cv2.INTER_CUBIC
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from oracle import resize as oresize
+        return oresize.resize_bicubic_u8(np.ascontiguousarray(img), int(w), int(h))
 
     cv2.resize = _resize
     sys.modules["cv2"] = cv2
@@ -329,9 +335,38 @@ def main():
            "classes": np.array([d["class"] for d in dets]),
            "probs": np.array([d["prob"] for d in dets], dtype=np.float64),
            "boxes": np.array([[d["x1"], d["y1"], d["x2"], d["y2"]] for d in dets], dtype=np.int64).reshape(-1, 4)}
+    # the same panel with the full-image pass on top of the tiles (C.include_full_img, RADNet.py:606-665): the whole image
+    # at the network size is one more source of detections, without a tile offset
+    def run_predict(Cq, rpn_seed, det_seed, images):
+        netq = rradnet.RADNet(Cq, FakeRPN(12, rpn_seed), FakeDetector(nc, det_seed), lambda x: x - np.float32(100.0))
+        with contextlib.redirect_stderr(io.StringIO()):
+            d = netq.predict(images)
+        return {"n": np.int64(len(d)), "classes": np.array([q["class"] for q in d]),
+                "probs": np.array([q["prob"] for q in d], dtype=np.float64),
+                "boxes": np.array([[q["x1"], q["y1"], q["x2"], q["y2"]] for q in d], dtype=np.int64).reshape(-1, 4)}
+    Cf = rconfig.Config(); Cf.tile_size = 600; Cf.tile_overlap = 300; Cf.img_size = 600; Cf.include_full_img = True
+    for k, v in run_predict(Cf, 8, 2, [img]).items():
+        pd_["full_" + k] = v
+    # full image only (no tiling: max_n_tiles_train = 0), two panels of different sizes, scaled 620x400 -> 465x300 and
+    # 350x500 -> 300x428 by the stubbed cv2.resize (oracle/resize.py): format_img's ratio and get_real_coordinates at work
+    Co = rconfig.Config(); Co.img_size = 300; Co.include_full_img = True; Co.max_n_tiles_train = 0
+    rs2 = np.random.RandomState(82)
+    img_a = rs2.randint(0, 256, (400, 620, 3)).astype(np.uint8)
+    img_b = rs2.randint(0, 256, (500, 350, 3)).astype(np.uint8)
+    pd_["only_img_a"], pd_["only_img_b"] = img_a, img_b
+    for k, v in run_predict(Co, 4, 6, [img_a, img_b]).items():
+        pd_["only_" + k] = v
     save("predict_fake", **pd_)
 
-    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+    mpath = os.path.join(OUT, "MANIFEST.json")
+    if os.path.exists(mpath):          # entries of the other generators (tools/gen_golden_feed.py, ...) stay
+        with open(mpath) as f:
+            prev = json.load(f)
+        for k, v in prev.items():
+            manifest.setdefault(k, v)
+        for k, v in prev.get("files", {}).items():
+            manifest["files"].setdefault(k, v)
+    with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote", sorted(manifest["files"]))
 

@@ -82,13 +82,19 @@ def main():
     out["selector"] = {"counts": [[k, v] for k, v in counts.items()], "seq": seq}      # pairs: the cycle follows dict order
 
     # ---- get_tile_generator -----------------------------------------------------------------------------------------
-    for name, seed, train, balanced, n_take, sizes in (("train_balanced", 5, True, True, 12, [(900, 700), (650, 1000), (300, 300), (760, 450)]),
-                                                       ("train_plain", 6, True, False, 10, [(900, 700), (450, 620), (300, 300)]),
-                                                       ("val", 7, False, True, 99, [(900, 700), (650, 1000), (300, 300)])):
+    # *_full cases: C.include_full_img (utils.py:484-549) -- after its tiles every image is yielded once more as a whole,
+    # scaled to the network size by cv2.resize, which the stub binds to oracle/resize.py (tools/gen_golden.py): they pin the
+    # reference's control flow, class balancing, random draws and anchor labels around the resize, not cv2's pixels
+    for name, seed, train, balanced, n_take, sizes, full in (("train_balanced", 5, True, True, 12, [(900, 700), (650, 1000), (300, 300), (760, 450)], False),
+                                                             ("train_plain", 6, True, False, 10, [(900, 700), (450, 620), (300, 300)], False),
+                                                             ("val", 7, False, True, 99, [(900, 700), (650, 1000), (300, 300)], False),
+                                                             ("train_plain_full", 8, True, False, 12, [(640, 480), (450, 620), (300, 300)], True),
+                                                             ("train_balanced_full", 9, True, True, 14, [(640, 480), (500, 700), (300, 300), (420, 330)], True),
+                                                             ("val_full", 10, False, False, 99, [(640, 480), (300, 300), (350, 520)], True)):
         C = rconfig.Config()
         C.img_size, C.tile_size, C.tile_overlap = 300, 300, 150
         C.max_n_tiles_train, C.max_n_tiles_val = 2, 3
-        C.balanced_classes, C.include_full_img, C.use_img_type = balanced, False, False
+        C.balanced_classes, C.include_full_img, C.use_img_type = balanced, full, False
         for k in ("use_horizontal_flips", "use_vertical_flips", "use_90_rotations", "use_rotations", "use_shear", "use_brightness", "use_noise"):
             setattr(C, k, False)
         data, imgs = dataset(seed, sizes, classes)
@@ -107,7 +113,7 @@ def main():
                                "img_sum": int(dbg.astype(np.int64).sum()), "n_pos": int(n_pos)})
         except (RuntimeError, StopIteration):        # val mode ends with `raise StopIteration` inside the generator (PEP 479)
             pass
-        out["cases"].append({"name": name, "seed": 100 + seed, "train": train, "balanced": balanced, "sizes": sizes, "data_seed": seed,
+        out["cases"].append({"name": name, "seed": 100 + seed, "train": train, "balanced": balanced, "sizes": sizes, "data_seed": seed, "full": full,
                              "yields": yields, "rng_after": int(np.random.randint(0, 2 ** 31 - 1))})
         print(name, len(yields), "yields")
     # ---- get_data ---------------------------------------------------------------------------------------------------
