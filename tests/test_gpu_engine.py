@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+from tolerances import check  # noqa: E402  (max-norm + per-channel + RMS criteria, tests/tolerances.py)
+
+
 def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     return np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
@@ -50,10 +53,10 @@ def test_rpn_forward_small_image(setup):
     rp = eng.rpn_forward(bp)
     pred = rp["pred"].cpu().numpy()
     assert Fg.shape == F.shape
-    assert rel_err(Fg.cpu().numpy(), F) < 1e-3
+    assert check(Fg.cpu().numpy(), F, 1e-3) < 1e-3
     A = eng.A
-    assert rel_err(pred[:, :A], p.reshape(-1, A)) < 1e-3
-    assert rel_err(pred[:, A:5 * A], r.reshape(-1, 4 * A)) < 1e-3
+    assert check(pred[:, :A], p.reshape(-1, A), 1e-3) < 1e-3
+    assert check(pred[:, A:5 * A], r.reshape(-1, 4 * A), 1e-3) < 1e-3
     assert np.all(pred[:, 5 * A:] == 0.0)
 
 
@@ -68,9 +71,9 @@ def test_cfg1_rpn_forward_600x800(setup):
     rp = eng.rpn_forward(bp)
     pred = rp["pred"].cpu().numpy()
     assert tuple(Fg.shape) == (1, 38, 50, 1024)
-    assert rel_err(Fg.cpu().numpy(), F) < 1e-3
-    assert rel_err(pred[:, :12], p.reshape(-1, 12)) < 1e-3
-    assert rel_err(pred[:, 12:60], r.reshape(-1, 48)) < 1e-3
+    assert check(Fg.cpu().numpy(), F, 1e-3) < 1e-3
+    assert check(pred[:, :12], p.reshape(-1, 12), 1e-3) < 1e-3
+    assert check(pred[:, 12:60], r.reshape(-1, 48), 1e-3) < 1e-3
     # proposals from the GPU's own scores: bit-exact vs the oracle run on the SAME tensors
     from oracle import glue
     R, Rn = eng.proposals(rp, 0.7, 300)
@@ -98,9 +101,9 @@ def test_head_forward_backward(setup):
     hp["rois"].copy_(torch.from_numpy(rois)); hp["y1"].copy_(torch.from_numpy(Y1[0])); hp["y2"].copy_(torch.from_numpy(Y2[0]))
     eng.head_forward(hp)
     pc, pr, cache = dense.head_forward(P, F, rois, 7)
-    assert rel_err(hp["feat"].cpu().numpy(), cache["feat"]) < 1e-3
-    assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 1e-3
-    assert rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 1e-3
+    assert check(hp["feat"].cpu().numpy(), cache["feat"], 1e-3) < 1e-3
+    assert check(hp["pcls"].cpu().numpy(), pc[0], 1e-3) < 1e-3
+    assert check(hp["pregr"].cpu().numpy(), pr[0], 1e-3) < 1e-3
     # ReLU ties: among ~10^6 activations a pre-activation can land within fp32 rounding of 0, positive in one
     # summation order and negative in another (which order runs depends on the launch configuration the autotuner
     # measured fastest).  The backward mask of such an element is then legitimately different; take the mask from
@@ -125,17 +128,17 @@ def test_head_forward_backward(setup):
     assert abs(got[2] - losses[3]) < 1e-6
     for name in eng.head_conv_names:
         c = eng.convs[name]
-        assert rel_err(c.dweight.cpu().numpy(), grads[name]["kernel"].reshape(-1, c.cout)) < 2e-3, name
-        assert rel_err(c.dbias.cpu().numpy(), grads[name]["bias"]) < 2e-3, name
+        assert check(c.dweight.cpu().numpy(), grads[name]["kernel"].reshape(-1, c.cout), 2e-3) < 2e-3, name
+        assert check(c.dbias.cpu().numpy(), grads[name]["bias"], 2e-3) < 2e-3, name
     dk = eng.dense_dw.cpu().numpy()
-    assert rel_err(dk[:, :7], grads["dense_class_7"]["kernel"]) < 2e-3
-    assert rel_err(dk[:, 7:31], grads["dense_regress_7"]["kernel"]) < 2e-3
+    assert check(dk[:, :7], grads["dense_class_7"]["kernel"], 2e-3) < 2e-3
+    assert check(dk[:, 7:31], grads["dense_regress_7"]["kernel"], 2e-3) < 2e-3
     # accumulate mode: a second backward doubles the gradients
     eng.set_accumulate(hp["bwd"], True)
     eng.head_backward(hp, accumulate=True)
     c = eng.convs["res5b_branch2b"]
-    assert rel_err(c.dweight.cpu().numpy(), 2 * grads["res5b_branch2b"]["kernel"].reshape(-1, c.cout)) < 2e-3
-    assert rel_err(eng.dense_dw.cpu().numpy()[:, :7], 2 * grads["dense_class_7"]["kernel"]) < 2e-3
+    assert check(c.dweight.cpu().numpy(), 2 * grads["res5b_branch2b"]["kernel"].reshape(-1, c.cout), 2e-3) < 2e-3
+    assert check(eng.dense_dw.cpu().numpy()[:, :7], 2 * grads["dense_class_7"]["kernel"], 2e-3) < 2e-3
 
 
 def test_full_train_step_vs_oracle():
@@ -497,8 +500,8 @@ def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
         eng.head_forward(hp)
     pc, pr, _ = dense.head_forward(P, F, rois, 7)
     for hp in (hi, ht):
-        assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 1e-3 and rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 1e-3
-    assert rel_err(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy()) < 2e-4
+        assert check(hp["pcls"].cpu().numpy(), pc[0], 1e-3) < 1e-3 and check(hp["pregr"].cpu().numpy(), pr[0], 1e-3) < 1e-3
+    assert check(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy(), 2e-4) < 2e-4
     before = hi["pregr"].cpu().numpy().copy()
     try:
         eng.head_arena.g.normal_(0, 1e-2)                                   # any gradient: the weights move by ~lr each
@@ -509,7 +512,7 @@ def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
             eng.head_forward(hp)
         moved = rel_err(hi["pregr"].cpu().numpy(), before)
         assert moved > 1e-3, moved                                          # the update is visible ...
-        assert rel_err(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy()) < 2e-4      # ... and both forms agree on it
+        assert check(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy(), 2e-4) < 2e-4      # ... and both forms agree on it
     finally:
         eng.set_weights(P)                                                  # module-scoped engine: restore
         eng.head_arena.g.zero_()

@@ -22,6 +22,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+from tolerances import check  # noqa: E402  (max-norm + per-channel + RMS criteria, tests/tolerances.py)
+
+
 def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     return np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
@@ -75,8 +78,8 @@ def test_cfg2_full_step_1000x600_vs_oracle():
     own = detail["R_own"]
     assert (own[:, None, :] == cap["R"][None, :, :]).all(-1).any(1).mean() > 0.9
     # post-update RPN outputs (Adam #1 applied on both sides)
-    assert rel_err(pred[:, :12], detail["p"].reshape(-1, 12)) < 1e-3
-    assert rel_err(pred[:, 12:60], detail["r"].reshape(-1, 48)) < 1e-3
+    assert check(pred[:, :12], detail["p"].reshape(-1, 12), 1e-3) < 1e-3
+    assert check(pred[:, 12:60], detail["r"].reshape(-1, 48), 1e-3) < 1e-3
     # RoI labelling and sampling on identical proposals: exact
     assert cap["keep"].sum() == detail["X2"].shape[1]
     assert np.array_equal(cap["cls"][cap["keep"]], detail["Y1"][0].argmax(-1))
@@ -115,11 +118,11 @@ def test_cfg2_full_step_1000x600_vs_oracle():
     # activations
     F_ref = detail["F"]
     assert tuple(Fg.shape) == F_ref.shape == (1, fh, fw, 1024)
-    assert rel_err(Fg.cpu().numpy(), F_ref) < 1e-3
+    assert check(Fg.cpu().numpy(), F_ref, 1e-3) < 1e-3
     P0 = copy.deepcopy(P)
     p0, r0, _ = dense.rpn_forward(P0, F_ref)
     pred0 = rp["pred"].cpu().numpy()
-    assert rel_err(pred0[:, :12], p0.reshape(-1, 12)) < 1e-3 and rel_err(pred0[:, 12:60], r0.reshape(-1, 48)) < 1e-3
+    assert check(pred0[:, :12], p0.reshape(-1, 12), 1e-3) < 1e-3 and check(pred0[:, 12:60], r0.reshape(-1, 48), 1e-3) < 1e-3
     # RPN backward: gradients straight out of the arena
     eng.set_accumulate(rp["bwd"], False, prezeroed=True)
     eng.rpn_backward(rp, ycls, yregr)
@@ -128,12 +131,12 @@ def test_cfg2_full_step_1000x600_vs_oracle():
     assert abs(l_rpn[0] - ref[0]) < 1e-3 * abs(ref[0]) and abs(l_rpn[1] - ref[1]) < 1e-3 * abs(ref[1]) + 1e-6
     g = detail["g_rpn"]
     c1, ch = eng.convs["rpn_conv1"], eng.convs["rpn_heads"]
-    assert rel_err(c1.dweight.cpu().numpy(), g["rpn_conv1"]["kernel"].reshape(-1, 512)) < 2e-3          # Winograd-domain wgrad
-    assert rel_err(c1.dbias.cpu().numpy()[:512], g["rpn_conv1"]["bias"]) < 2e-3
+    assert check(c1.dweight.cpu().numpy(), g["rpn_conv1"]["kernel"].reshape(-1, 512), 2e-3) < 2e-3          # Winograd-domain wgrad
+    assert check(c1.dbias.cpu().numpy()[:512], g["rpn_conv1"]["bias"], 2e-3) < 2e-3
     dwh, dbh = ch.dweight.cpu().numpy(), ch.dbias.cpu().numpy()
-    assert rel_err(dwh[:, :12], g["rpn_out_class"]["kernel"].reshape(512, 12)) < 2e-3
-    assert rel_err(dwh[:, 12:60], g["rpn_out_regress"]["kernel"].reshape(512, 48)) < 2e-3
-    assert rel_err(dbh[:12], g["rpn_out_class"]["bias"]) < 2e-3 and rel_err(dbh[12:60], g["rpn_out_regress"]["bias"]) < 2e-3
+    assert check(dwh[:, :12], g["rpn_out_class"]["kernel"].reshape(512, 12), 2e-3) < 2e-3
+    assert check(dwh[:, 12:60], g["rpn_out_regress"]["kernel"].reshape(512, 48), 2e-3) < 2e-3
+    assert check(dbh[:12], g["rpn_out_class"]["bias"], 2e-3) < 2e-3 and check(dbh[12:60], g["rpn_out_regress"]["bias"], 2e-3) < 2e-3
     assert np.all(dwh[:, 60:] == 0) and np.all(dbh[60:] == 0)
     # classifier phase on the oracle's sampled RoIs / targets (identical to the device's, asserted above): direct gradients
     sel = detail["sel"]
@@ -150,11 +153,11 @@ def test_cfg2_full_step_1000x600_vs_oracle():
     assert abs(l_det[0] - ref[2]) < 2e-3 * abs(ref[2]) and abs(l_det[1] - ref[3]) < 2e-3 * abs(ref[3]) + 1e-5
     for name in eng.head_conv_names:
         c = eng.convs[name]
-        assert rel_err(c.dweight.cpu().numpy(), gh[name]["kernel"].reshape(-1, c.cout)) < 2e-3, name
-        assert rel_err(c.dbias.cpu().numpy(), gh[name]["bias"]) < 2e-3, name
+        assert check(c.dweight.cpu().numpy(), gh[name]["kernel"].reshape(-1, c.cout), 2e-3) < 2e-3, name
+        assert check(c.dbias.cpu().numpy(), gh[name]["bias"], 2e-3) < 2e-3, name
     dk, db = eng.dense_dw.cpu().numpy(), eng.dense_db.cpu().numpy()
-    assert rel_err(dk[:, :7], gh["dense_class_7"]["kernel"]) < 2e-3 and rel_err(dk[:, 7:31], gh["dense_regress_7"]["kernel"]) < 2e-3
-    assert rel_err(db[:7], gh["dense_class_7"]["bias"]) < 2e-3 and rel_err(db[7:31], gh["dense_regress_7"]["bias"]) < 2e-3
+    assert check(dk[:, :7], gh["dense_class_7"]["kernel"], 2e-3) < 2e-3 and check(dk[:, 7:31], gh["dense_regress_7"]["kernel"], 2e-3) < 2e-3
+    assert check(db[:7], gh["dense_class_7"]["bias"], 2e-3) < 2e-3 and check(db[7:31], gh["dense_regress_7"]["bias"], 2e-3) < 2e-3
 
 
 def test_cfg3_predict_tile_2048_at_img_size_600_vs_oracle():
@@ -180,7 +183,7 @@ def test_cfg3_predict_tile_2048_at_img_size_600_vs_oracle():
     Y1, Y2, F = m_rpn3.predict(X)
     p, r, F_ref = ostep.rpn_only_forward(P, small)
     assert F.shape == F_ref.shape == (1, 38, 38, 1024)
-    assert rel_err(F, F_ref) < 1e-3 and rel_err(Y1, p) < 1e-3 and rel_err(Y2, r) < 1e-3
+    assert check(F, F_ref, 1e-3) < 1e-3 and check(Y1, p, 1e-3) < 1e-3 and check(Y2, r, 1e-3) < 1e-3
     # proposals on the device's own tensors: bit-exact
     R = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
     assert np.array_equal(R, glue.rpn_to_roi(Y1, Y2, C, True, 300, 0.7))
@@ -221,8 +224,8 @@ def test_cfg5_vgg16_base_and_rpn_1000x600_vs_oracle():
     rp = eng.rpn_forward(bp)
     pred = rp["pred"].cpu().numpy()
     assert tuple(Fg.shape) == F.shape == (1, 37, 62, 512)
-    assert rel_err(Fg.cpu().numpy(), F) < 1e-3
-    assert rel_err(pred[:, :9], p.reshape(-1, 9)) < 1e-3 and rel_err(pred[:, 9:45], r.reshape(-1, 36)) < 1e-3
+    assert check(Fg.cpu().numpy(), F, 1e-3) < 1e-3
+    assert check(pred[:, :9], p.reshape(-1, 9), 1e-3) < 1e-3 and check(pred[:, 9:45], r.reshape(-1, 36), 1e-3) < 1e-3
     R, Rn = eng.proposals(rp, 0.7, 300)
     n = int(Rn.cpu()[0])
     Rref = glue.rpn_to_roi(pred[:, :9].reshape(1, 37, 62, 9), pred[:, 9:45].reshape(1, 37, 62, 36), C, True, 300, 0.7)
@@ -302,7 +305,7 @@ def test_cfg3_predict_tile_2048_at_img_size_1000_rpn_and_proposals_vs_oracle():
     Y1, Y2, F = m_rpn3.predict(X)
     p, r, F_ref = ostep.rpn_only_forward(P, small)
     assert F.shape == F_ref.shape == (1, 63, 63, 1024)
-    assert rel_err(F, F_ref) < 1e-3 and rel_err(Y1, p) < 1e-3 and rel_err(Y2, r) < 1e-3
+    assert check(F, F_ref, 1e-3) < 1e-3 and check(Y1, p, 1e-3) < 1e-3 and check(Y2, r, 1e-3) < 1e-3
     R = rpn.rpn_to_roi(Y1, Y2, C, overlap_thresh=0.7)
     assert np.array_equal(R, glue.rpn_to_roi(Y1, Y2, C, True, 300, 0.7))
     Rx = R[:20].copy()

@@ -98,6 +98,8 @@ def test_conv_fwd(ctx, case):
     ctx.check(ctx.lib.radnet_conv_fwd(ctx.h, C.byref(d)), "conv_fwd")
     ctx.sync()
     close(y.cpu().numpy(), ref)
+    from tolerances import check
+    check(y.cpu().numpy(), ref, 2e-4, "conv_fwd %s" % (case,))        # + per output channel and RMS (tests/tolerances.py)
 
 
 def test_conv_fwd_sigmoid_head_columns(ctx):

@@ -63,12 +63,13 @@ def test_calc_region_props_matches_reference_goldens():
 
 
 class _FakeDet:
-    def __init__(self, nc, seed):
-        from test_oracle_glue import fake_detector
-        self._f = fake_detector(nc, seed, [])
+    def __init__(self, nc, seed, tie_free=False):
+        from test_oracle_glue import fake_detector, fake_detector_tie_free
+        self._f = (fake_detector_tie_free if tie_free else fake_detector)(nc, seed, [])
+        self._tie_free = tie_free
 
     def predict(self, inputs):
-        return self._f(inputs[1])
+        return self._f(inputs[1], inputs[0]) if self._tie_free else self._f(inputs[1])
 
 
 class _FakeRPN:
@@ -125,8 +126,11 @@ def test_radnet_predict_full_image_pass_matches_reference_output():
     _same_detections(net.predict([g["img"]]), g, "full_")
     assert int(g["full_n"]) != int(g["n"])                       # the pass changes the result
     C = Config(); C.img_size = 300; C.include_full_img = True; C.max_n_tiles_train = 0
-    net = RADNet(C, _FakeRPN(12, 4), _FakeDet(7, 6), lambda x: x - np.float32(100.0))
-    _same_detections(net.predict([g["only_img_a"], g["only_img_b"]]), g, "only_")
+    net = RADNet(C, _FakeRPN(12, 4), _FakeDet(7, 6, tie_free=True), lambda x: x - np.float32(100.0))
+    dets = net.predict([g["only_img_a"], g["only_img_b"]])
+    _same_detections(dets, g, "only_")
+    assert [d["class"] for d in dets] == list(g["only_classes"])                 # tie-free scores: the ORDER is pinned too
+    assert np.array_equal(np.array([[d["x1"], d["y1"], d["x2"], d["y2"]] for d in dets]), g["only_boxes"])
 
 
 def test_tile_feed_full_image_pass_device_resize():

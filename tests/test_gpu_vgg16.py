@@ -10,6 +10,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+from tolerances import check  # noqa: E402  (max-norm + per-channel + RMS criteria, tests/tolerances.py)
+
+
 def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     return np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
@@ -51,8 +54,8 @@ def test_vgg_rpn_forward_and_proposals(setup):
     rp = eng.rpn_forward(bp)
     pred = rp["pred"].cpu().numpy()
     assert tuple(Fg.shape) == F.shape == (1, 12, 20, 512)
-    assert rel_err(Fg.cpu().numpy(), F) < 1e-3
-    assert rel_err(pred[:, :9], p.reshape(-1, 9)) < 1e-3 and rel_err(pred[:, 9:45], r.reshape(-1, 36)) < 1e-3
+    assert check(Fg.cpu().numpy(), F, 1e-3) < 1e-3
+    assert check(pred[:, :9], p.reshape(-1, 9), 1e-3) < 1e-3 and check(pred[:, 9:45], r.reshape(-1, 36), 1e-3) < 1e-3
     R, Rn = eng.proposals(rp, 0.7, 300)
     n = int(Rn.cpu()[0])
     Rref = glue.rpn_to_roi(pred[:, :9].reshape(1, 12, 20, 9), pred[:, 9:45].reshape(1, 12, 20, 36), C, True, 300, 0.7)
@@ -73,8 +76,8 @@ def test_vgg_head_variable_rois(setup, R):
     hp["rois"].copy_(torch.from_numpy(rois))
     eng.head_forward(hp, training=False)
     pc, pr, cache = vgg.head_forward(P, F, rois, 7, None)
-    assert rel_err(hp["h1"].cpu().numpy(), cache["h1"]) < 1e-3
-    assert rel_err(hp["pcls"].cpu().numpy(), pc[0]) < 2e-3 and rel_err(hp["pregr"].cpu().numpy(), pr[0]) < 2e-3
+    assert check(hp["h1"].cpu().numpy(), cache["h1"], 1e-3) < 1e-3
+    assert check(hp["pcls"].cpu().numpy(), pc[0], 2e-3) < 2e-3 and check(hp["pregr"].cpu().numpy(), pr[0], 2e-3) < 2e-3
     if R > 40:
         return
     cls = rs.randint(0, 7, R)
@@ -97,11 +100,11 @@ def test_vgg_head_variable_rois(setup, R):
     assert abs(got[0] - losses[1]) < 2e-3 * abs(losses[1]) and abs(got[1] - losses[2]) < 2e-3 * abs(losses[2]) + 1e-6
     for name in ("fc1", "fc2"):
         c = eng.convs[name]
-        assert rel_err(c.dweight.cpu().numpy(), grads[name]["kernel"]) < 3e-3, name
-        assert rel_err(c.dbias.cpu().numpy(), grads[name]["bias"]) < 3e-3, name
+        assert check(c.dweight.cpu().numpy(), grads[name]["kernel"], 3e-3) < 3e-3, name
+        assert check(c.dbias.cpu().numpy(), grads[name]["bias"], 3e-3) < 3e-3, name
     dk = eng.dense_dw.cpu().numpy()
-    assert rel_err(dk[:, :7], grads["dense_class_7"]["kernel"]) < 3e-3
-    assert rel_err(dk[:, 7:31], grads["dense_regress_7"]["kernel"]) < 3e-3
+    assert check(dk[:, :7], grads["dense_class_7"]["kernel"], 3e-3) < 3e-3
+    assert check(dk[:, 7:31], grads["dense_regress_7"]["kernel"], 3e-3) < 3e-3
 
 
 def test_vgg_train_step_runs_and_learns(setup):

@@ -119,6 +119,21 @@ def fake_detector(nc, seed, calls):
     return predict
 
 
+def fake_detector_tie_free(nc, seed, calls):
+    """tools/gen_golden.py: FakeDetectorTieFree (distinct RoIs, and the same RoI on distinct feature maps -> distinct
+    probabilities)."""
+    def predict(rois, F):
+        calls.append(np.array(rois))
+        r = np.asarray(rois)[0].astype(np.float64)
+        key = (r * np.array([3.0 ** 0.5, 5.0 ** 0.5, 7.0 ** 0.5, 11.0 ** 0.5])).sum(1) + seed + float(np.abs(np.asarray(F, dtype=np.float64)).sum()) % 7.0
+        logits = np.stack([np.sin(key * (k + 1) * 0.37) * 4.0 for k in range(nc)], 1)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        p = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        regr = np.stack([np.cos(key * (k + 1) * 0.11) * 2.0 for k in range(4 * (nc - 1))], 1).astype(np.float32)
+        return [p[None], regr[None]]
+    return predict
+
+
 def test_spp_decode():
     g = load_golden("spp")
     C = Config()

@@ -1,0 +1,56 @@
+"""The stated floating-point tolerance of the dense parity tests (fp32 MFMA accumulation, Winograd re-association and fused
+FMA epilogues on the device against the oracle's float64 / BLAS sums), as ONE checker with three criteria:
+
+  1. max-norm       max|a - b| <= tol * max|b|                          (what the suite asserted through round 2)
+  2. per channel    for every channel c of the last axis:  max|a - b| over c <= tol * max|b_c| + FLOOR * tol * max|b|
+                    -- a wrong low-magnitude channel, or a dropped border column of a 1024-channel map, passes (1) but not
+                    (2): the bound follows the channel's own scale, plus a floor of 1e-3 of the global bound for channels that
+                    are (almost) dead after their ReLU (FLOOR; an fp32 sum of O(1) terms lands ~1e-6 * max|b| from zero)
+  3. RMS            ||a - b||_2 <= RMS_FRACTION * tol * ||b||_2          (errors must look like rounding noise -- centred, a
+                    tenth of the worst-case bound -- not like a systematic offset that happens to stay under (1))
+
+`tol` is the figure each test states (activations 1e-3, gradients 2e-3, VGG fc gradients 3e-3).  One-dimensional arrays (bias
+gradients) have no channel axis: criteria 1 and 3.  RADNET_TOL_REPORT=1 prints the three measured ratios per call instead of
+asserting (used once per round on the GPU box to see how far below the bounds the kernels sit; profiles/r03_tolerance_report.txt)."""
+import os
+
+import numpy as np
+
+FLOOR = 1e-3
+RMS_FRACTION = 0.1
+_REPORT = os.environ.get("RADNET_TOL_REPORT", "0") == "1"
+
+
+def measure(a, b):
+    """-> (max-norm ratio, worst per-channel excess ratio [<= 1 passes when scaled by tol], rms ratio)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = np.abs(a - b)
+    gmax = max(np.abs(b).max(), 1e-30)
+    max_ratio = d.max() / gmax
+    rms_ratio = np.sqrt((d * d).sum()) / max(np.sqrt((b * b).sum()), 1e-30)
+    chan = None
+    if a.ndim >= 2 and a.shape[-1] > 1:
+        dc = d.reshape(-1, a.shape[-1]).max(0)
+        bc = np.abs(b).reshape(-1, b.shape[-1]).max(0)
+        chan = dc / (bc + FLOOR * gmax)           # compared with tol
+    return max_ratio, chan, rms_ratio
+
+
+def check(a, b, tol, what=""):
+    if not what:                                   # the call site names the comparison
+        import sys
+        f = sys._getframe(1)
+        what = "%s:%d" % (os.path.basename(f.f_code.co_filename), f.f_lineno)
+    max_ratio, chan, rms_ratio = measure(a, b)
+    worst = float(chan.max()) if chan is not None else float("nan")
+    if _REPORT:
+        print("[tol] %-44s tol %.0e  max-norm %.2e  worst-channel %.2e  rms %.2e (bound %.0e)" % (what, tol, max_ratio, worst, rms_ratio, RMS_FRACTION * tol))
+        return max_ratio
+    assert max_ratio < tol, "%s: max-norm error %.3e >= %.1e" % (what, max_ratio, tol)
+    if chan is not None:
+        c = int(chan.argmax())
+        assert worst < tol, "%s: channel %d is off by %.3e of its own scale (+ floor) >= %.1e" % (what, c, worst, tol)
+    assert rms_ratio < RMS_FRACTION * tol, "%s: RMS relative error %.3e >= %.1e" % (what, rms_ratio, RMS_FRACTION * tol)
+    return max_ratio

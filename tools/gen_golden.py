@@ -337,8 +337,22 @@ def main():
            "boxes": np.array([[d["x1"], d["y1"], d["x2"], d["y2"]] for d in dets], dtype=np.int64).reshape(-1, 4)}
     # the same panel with the full-image pass on top of the tiles (C.include_full_img, RADNet.py:606-665): the whole image
     # at the network size is one more source of detections, without a tile offset
-    def run_predict(Cq, rpn_seed, det_seed, images):
-        netq = rradnet.RADNet(Cq, FakeRPN(12, rpn_seed), FakeDetector(nc, det_seed), lambda x: x - np.float32(100.0))
+    class FakeDetectorTieFree(FakeDetector):
+        """As FakeDetector, with irrational RoI weights and a softer softmax: distinct RoIs get distinct probabilities, so the
+        result does not hang on np.argsort's order among EQUAL scores (SURVEY.md A.4 rule 6) -- with two panels and the
+        cross-image NMS that order changes which boxes survive."""
+        def predict(self, inputs):
+            F, rois = inputs
+            r = np.asarray(rois)[0].astype(np.float64)
+            # + a term from the feature map: the same RoI proposed on two panels must not score the same on both
+            key = (r * np.array([3.0 ** 0.5, 5.0 ** 0.5, 7.0 ** 0.5, 11.0 ** 0.5])).sum(1) + self.seed + float(np.abs(np.asarray(F, dtype=np.float64)).sum()) % 7.0
+            logits = np.stack([np.sin(key * (k + 1) * 0.37) * 4.0 for k in range(self.nc)], 1)
+            e = np.exp(logits - logits.max(1, keepdims=True)); p = (e / e.sum(1, keepdims=True)).astype(np.float32)
+            regr = np.stack([np.cos(key * (k + 1) * 0.11) * 2.0 for k in range(4 * (self.nc - 1))], 1).astype(np.float32)
+            return [p[None], regr[None]]
+
+    def run_predict(Cq, rpn_seed, det_seed, images, tie_free=False):
+        netq = rradnet.RADNet(Cq, FakeRPN(12, rpn_seed), (FakeDetectorTieFree if tie_free else FakeDetector)(nc, det_seed), lambda x: x - np.float32(100.0))
         with contextlib.redirect_stderr(io.StringIO()):
             d = netq.predict(images)
         return {"n": np.int64(len(d)), "classes": np.array([q["class"] for q in d]),
@@ -354,8 +368,9 @@ def main():
     img_a = rs2.randint(0, 256, (400, 620, 3)).astype(np.uint8)
     img_b = rs2.randint(0, 256, (500, 350, 3)).astype(np.uint8)
     pd_["only_img_a"], pd_["only_img_b"] = img_a, img_b
-    for k, v in run_predict(Co, 4, 6, [img_a, img_b]).items():
+    for k, v in run_predict(Co, 4, 6, [img_a, img_b], tie_free=True).items():
         pd_["only_" + k] = v
+    assert len(set(pd_["only_probs"].tolist())) == len(pd_["only_probs"]), "tie-free detector produced equal scores"
     save("predict_fake", **pd_)
 
     mpath = os.path.join(OUT, "MANIFEST.json")
