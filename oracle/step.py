@@ -118,6 +118,61 @@ class OracleTrainerCont(OracleTrainer):
         return [l_cls, l_regr, lc, lr_, dense.categorical_accuracy(Y1[:, sel].astype(np.float32), pc)]
 
 
+class OracleTrainerVGG(OracleTrainer):
+    """The same iteration with the VGG16 base model (BASELINE cfg 5; vgg16.py:29-124): block1..5 frozen as train.py freezes
+    every base model, rpn_layer on the 512-channel map, classifier = RoI crop-resize 7x7 -> fc1 -> Dropout -> fc2 -> Dropout
+    -> two dense heads.  TF's dropout RNG cannot be matched, so the two keep-masks of a step (already x2) are handed in
+    (`masks`), as oracle/vgg.py documents; a test gives the device path the same masks."""
+
+    def __init__(self, C, P, lr=5e-5, keras2_bce=True):
+        from . import vgg
+        self.vgg = vgg
+        self.C, self.P = C, P
+        self.A = len(C.anchor_box_scales) * len(C.anchor_box_ratios)
+        self.nc = len(C.class_mapping)
+        self.keras2_bce = keras2_bce
+        self.opt_rpn = dense.AdamState(P, dense.RPN_TRAINABLE, lr)
+        self.opt_head = dense.AdamState(P, list(vgg.HEAD_TRAINABLE) + ["dense_class_%d" % self.nc, "dense_regress_%d" % self.nc], lr)
+
+    def targets(self, sample):
+        C = self.C
+        H, W = sample["img"].shape[:2]
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in sample["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        isbg = np.array([1 if b["class"] == "bg" else 0 for b in sample["bboxes"]])
+        fs = lambda w, h: (glue.vgg16_feat_len(w), glue.vgg16_feat_len(h))
+        ycls, yregr, _, _ = glue.anchor_targets(C, gt, isbg, sample["width"], sample["height"], W, H, fs)
+        return glue.to_train_layout(ycls, yregr, C.std_scaling)
+
+    def step(self, sample, detail=None, override_R=None, masks_fn=None):
+        """masks_fn(R) -> (m1, m2) keep-masks [R][4096] x2 for the classifier pass (None: no dropout, i.e. inference arithmetic)."""
+        C, P, vgg = self.C, self.P, self.vgg
+        y_cls, y_regr = self.targets(sample)
+        F = vgg.base_forward(P, dense.preprocess_caffe_bgr(sample["img"]))
+        l_rpn, g_rpn = dense.rpn_losses_and_grads(P, F, y_cls.astype(np.float32), y_regr.astype(np.float32), self.A, self.keras2_bce)
+        self.opt_rpn.apply(P, g_rpn)
+        p, r, _ = dense.rpn_forward(P, F)
+        R = glue.rpn_to_roi(p, r, C, use_regr=True, overlap_thresh=0.7, max_boxes=300)
+        if detail is not None:
+            detail["R_own"] = R
+        if override_R is not None:
+            R = override_R
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in sample["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        gcls = np.array([C.class_mapping[b["class"]] for b in sample["bboxes"]])
+        X2, Y1, Y2, _ = glue.roi_targets(R, gt, gcls, sample["width"], sample["height"], C)
+        if detail is not None:
+            detail.update(F=F, g_rpn=g_rpn, p=p, r=r, R=R, X2=X2, Y1=Y1, Y2=Y2)
+        if X2 is None:
+            return [l_rpn[1], l_rpn[2], None, None, None]
+        sel, _ = glue.select_samples(Y1, C.n_rois)
+        masks = masks_fn(len(sel)) if masks_fn is not None else None
+        l_det, g_head = vgg.head_losses_and_grads(P, F, X2[0, sel].astype(np.float32), Y1[:, sel].astype(np.float32),
+                                                  Y2[:, sel].astype(np.float32), self.nc, masks)
+        self.opt_head.apply(P, g_head)
+        if detail is not None:
+            detail.update(sel=sel, g_head=g_head)
+        return [l_rpn[1], l_rpn[2], l_det[1], l_det[2], l_det[3]]
+
+
 def _acc(total, g):
     if total is None:
         return {n: {k: v.astype(np.float64).copy() for k, v in d.items()} for n, d in g.items()}

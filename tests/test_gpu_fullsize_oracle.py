@@ -230,6 +230,37 @@ def test_cfg5_vgg16_base_and_rpn_1000x600_vs_oracle():
     n = int(Rn.cpu()[0])
     Rref = glue.rpn_to_roi(pred[:, :9].reshape(1, 37, 62, 9), pred[:, 9:45].reshape(1, 37, 62, 36), C, True, 300, 0.7)
     assert n == len(Rref) and np.array_equal(R.cpu().numpy()[:n], Rref)
+    # RPN backward at full size: rpn_conv1 (3x3, C = 512 -> 512) and the two 1x1 heads, gradients straight out of the arena
+    from oracle import step as ostep
+    from radnet_hip.trainer import TrainStep
+    meta = synth.synthetic_gt(2, n=8, src_w=2000, src_h=1200)
+    sample = dict(img=img, bboxes=meta["bboxes"], width=2000, height=1200)
+    ot = ostep.OracleTrainerVGG(C, copy.deepcopy(P))
+    np.random.seed(64)
+    yc_ref, yr_ref = ot.targets(sample)
+    ts = TrainStep(eng)
+    np.random.seed(64)
+    tp = eng.anchor_targets_launch(ts._gt(sample), sample["width"], sample["height"], 1000, 600, slot=91)
+    ycls, yregr, n_pos = eng.anchor_targets_finish(tp)
+    assert np.array_equal(ycls.cpu().numpy().reshape(yc_ref.shape), yc_ref.astype(np.float32))          # 9 anchors, 37x62 map
+    assert np.array_equal(yregr.cpu().numpy().reshape(yr_ref.shape), yr_ref.astype(np.float32))
+    l_ref, g = dense.rpn_losses_and_grads(P, F, yc_ref.astype(np.float32), yr_ref.astype(np.float32), 9, True)
+    for arena in (eng.rpn_arena,):
+        arena.g.zero_()
+    eng.set_accumulate(rp["bwd"], False, prezeroed=True)
+    eng.rpn_backward(rp, ycls, yregr)
+    torch.cuda.synchronize()
+    l_rpn = eng.rpn_losses.cpu().numpy()
+    assert abs(l_rpn[0] - l_ref[1]) < 1e-3 * abs(l_ref[1]) and abs(l_rpn[1] - l_ref[2]) < 1e-3 * abs(l_ref[2]) + 1e-6
+    c1, ch = eng.convs["rpn_conv1"], eng.convs["rpn_heads"]
+    assert check(c1.dweight.cpu().numpy(), g["rpn_conv1"]["kernel"].reshape(-1, 512), 2e-3) < 2e-3
+    assert check(c1.dbias.cpu().numpy()[:512], g["rpn_conv1"]["bias"], 2e-3) < 2e-3
+    dwh, dbh = ch.dweight.cpu().numpy(), ch.dbias.cpu().numpy()
+    assert check(dwh[:, :9], g["rpn_out_class"]["kernel"].reshape(512, 9), 2e-3) < 2e-3
+    assert check(dwh[:, 9:45], g["rpn_out_regress"]["kernel"].reshape(512, 36), 2e-3) < 2e-3
+    assert check(dbh[:9], g["rpn_out_class"]["bias"], 2e-3) < 2e-3 and check(dbh[9:45], g["rpn_out_regress"]["bias"], 2e-3) < 2e-3
+    assert np.all(dwh[:, 45:] == 0) and np.all(dbh[45:] == 0)
+    eng.rpn_arena.g.zero_()
 
 
 def test_cfg4_per_gpu_batch_2_at_1000x600_one_program_vs_oracle():
