@@ -333,11 +333,12 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  *   SCATTER      p: src, mask|0, dst         i: nb, oh, ow, c, stride, h, w
  *   FILL0        p: dst                      i: bytes (low 32 bits), bytes (high 32 bits)
  *   RELU_MASK    p: g, act                   i: n (low), n (high)
- *   ROI_BWD      p: dy, rois, dfmap          i: h, w, c, r, ps */
+ *   ROI_BWD      p: dy, rois, dfmap          i: h, w, c, r, ps
+ *   CHAIN        p: radnet_chain*             (radnet_chain_run: a run of CONV_FWD / WINO ops as one persistent launch) */
 enum {
   RADNET_OP_CONV_FWD = 1, RADNET_OP_CONV_DGRAD = 2, RADNET_OP_CONV_WGRAD = 3, RADNET_OP_MAXPOOL = 4, RADNET_OP_COLSUM = 5,
   RADNET_OP_WINO = 6, RADNET_OP_WINO_REUSE = 7, RADNET_OP_WINO_WGRAD = 8, RADNET_OP_SCATTER = 9, RADNET_OP_FILL0 = 10,
-  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_NOP = 0
+  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_CHAIN = 14, RADNET_OP_NOP = 0
 };
 typedef struct radnet_op {
   int32_t kind;
@@ -346,6 +347,25 @@ typedef struct radnet_op {
   radnet_conv_desc conv;
 } radnet_op;
 int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops);
+
+/* ---- a run of dependent layers as ONE persistent launch ("chain"; resnet50.py:150-228 nn_base, stages 2-4) --------------
+ * radnet_chain_build turns a list of CONV_FWD (channels a multiple of 32) and WINO (form 4) ops -- the same radnet_op[] that
+ * radnet_program_run would launch one by one -- into a list of work items (output tiles, transform blocks) in dependency
+ * order plus arrival counters; radnet_chain_run launches `workgroups` persistent workgroups (0: two per CU) that draw the
+ * items and start each as soon as the blocks it reads are complete.  Same kernels' code, same arithmetic per output element
+ * as the launches it replaces for the convs (64x64 tiles; K-split layers add their slices in slice order); what goes away
+ * is the gap between dependent launches, their lockstep prologue / epilogue phases and their tails.  A narrow
+ * grid leaves CU slots to launches on other streams.  RADNET_ERR_UNSUPPORTED for an op the chain cannot run: the caller
+ * keeps radnet_program_run.  The chain holds device memory of its own (items, counters, K-split slabs): build it outside
+ * stream capture; radnet_chain_run allocates nothing and can be captured.  radnet_chain_status synchronises the stream;
+ * last_error != 0: a workgroup waited ~seconds for an input block that never completed (1 + item index; the launch still
+ * drains and can be replayed, its outputs are invalid). */
+typedef struct radnet_chain radnet_chain;
+int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out);
+int radnet_chain_run(radnet_ctx* ctx, radnet_chain* chain);
+int radnet_chain_status(radnet_ctx* ctx, radnet_chain* chain, int32_t* last_error, int32_t* runs, int32_t* n_items, int32_t* n_stages,
+                        double* flops_executed, double* flops_algorithmic);
+void radnet_chain_destroy(radnet_chain* chain);
 
 /* model_rpn.predict (RADNet.py:552; train.py:291): nn_base program, then rpn_layer program (outputs where the programs'
  * descriptors point: the fused head matrix [fh*fw][ld] with the sigmoid scores in columns [0,A), regressions in [A,5A)). */

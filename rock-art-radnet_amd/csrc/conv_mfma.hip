@@ -27,6 +27,7 @@
 //     from limiting; what matters is filling 256 CUs at batch 1 -- tile shape, K slices, workgroup order and waves per
 //     workgroup are measured per problem shape (run_igemm).
 #include "radnet_internal.h"
+#include "radnet_wino4.h"
 #include <hip/hip_ext.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -264,7 +265,9 @@ __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB,
 template <int BM, int BN, int BMODE>
 constexpr int igemm_lds_floats() { return 2 * (BM * kRowPitch + ((BMODE == 0) ? BK * (BN + 4) : BN * kRowPitch)); }
 
-template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
+// COH: the output is handed to other workgroups of the SAME launch (chain kernel): stores are write-through (sc1), as the
+// split-K slabs are, so that a consumer on another XCD finds them in memory.
+template <int BM, int BN, int BMODE, bool SMALLC, int WAVES, bool COH = false>
 __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __restrict__ lds, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
                                                 const unsigned grid_x) {
   constexpr int NT = 64 * WAVES;
@@ -731,7 +734,8 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
 #ifdef RADNET_DIAG_SKIP_EPILOGUE
         if (r != 0) { asm volatile("" ::"v"(v)); continue; }
 #endif
-        buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
+        if (COH) buf_store1_sc1(ry, vy + row * ldy4, v);
+        else buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
       }
     }
   }
@@ -1391,6 +1395,221 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   return RADNET_OK;
 }
 
+
+// =====================================================================================================================
+// Chain kernel: a run of dependent layers as ONE persistent launch
+// =====================================================================================================================
+// nn_base (resnet50.py:150-228) at batch 1 is ~50 dependent launches of 10-25 us.  Each loses 2 us to the gap behind
+// the previous launch, 2 + 3 us to prologue / epilogue phases that all of its workgroups pass through together, and a tail in
+// which the CUs with one workgroup fewer idle (profiles/r02_workgroup_stamps.txt) -- about half of the 0.95 ms the chain
+// takes alone on the chip.  Here the whole run is one launch of `grid` persistent workgroups that draw WORK ITEMS -- one
+// output tile of a conv (conv_igemm_body: the same code the layer launches run), or a block of a Winograd transform -- from
+// a list the host wrote in dependency order, and start an item as soon as the items it reads from have finished:
+//   * every stage (conv, Winograd input transform, batched Winograd GEMM, output transform) owns arrival counters over
+//     blocks of its output (64 rows of a conv output, 64 tiles of a transformed operand, one tile row of a Winograd layer's
+//     output); a finished item adds 1 to the counters of the blocks it wrote, an item waits until the blocks it reads have
+//     reached the count the host computed for them (`need`);
+//   * hand-off between workgroups is the split-K protocol of conv_igemm_body: outputs are written through (sc1 stores),
+//     the writer drains them (vmcnt(0)) and bumps the counter with a relaxed agent-scope atomic, the reader polls the counter
+//     with agent-scope loads.  Consumers read the data with ordinary loads: a line of an activation tensor is complete before
+//     any workgroup may touch it (the counters cover whole rows of whole tiles, tensors are not shared, a launch starts with
+//     clean caches), so no cache on the reader's side can hold an older copy;
+//   * items are drawn with one atomic per workgroup in list order and the list is topologically sorted, so the lowest
+//     unfinished item is always held by a running workgroup whose inputs are finished or running: no deadlock for any grid
+//     size; a poll that does not see its counters move within ~2 s raises `error` and every workgroup leaves (the grid
+//     always drains);
+//   * the last workgroup to leave zeroes the counters and the queue head: the launch can be replayed (hipGraph).
+// A narrow grid (1-2 workgroups per CU) leaves CU slots to the other lanes' launches: the frozen base forward of an announced
+// batch is background work in the pipelined step.
+struct ChainStage {
+  GemmArgs g;                                   // type 0: conv tile / tile of a batched GEMM
+  const float* t_src;                           // type 1: x [nb][h][w][c] -> V;  type 2: M [36][T][n] -> y
+  float* t_dst;
+  const float* t_scale;
+  const float* t_shift;
+  int t_nb, t_h, t_w, t_c, t_th, t_tw, t_act, t_ldy;
+  unsigned t_dst_bytes;
+  int type;
+};
+struct ChainItem {
+  int stage, bx, by, bz;
+  int d0_first, d0_count, d1_first, d1_count;   // counter ranges that must have reached their `need`
+  int sig0, sig1, pad0, pad1;                   // counters this item bumps when done (-1: none)
+};
+struct ChainHeader {
+  unsigned next, exited, error, last_error;
+  unsigned runs, pad[3];
+};
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void buf_store2_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v) {
+  f32x2v f = {v.x, v.y};
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f), r, (int)off, 0, 16);
+}
+
+// One block (256 units: a unit = one tile x 1 channel: 36 live registers, so the item does not
+// raise the register budget of the GEMM items it shares the kernel with) of the F(4x4,3x3) input transform, write-through stores.
+__device__ __forceinline__ void chain_wino4_input(const ChainStage& st, unsigned block) {
+  typedef float VT;
+  const int cv = st.t_c, H = st.t_h, W_ = st.t_w, C = st.t_c, TH = st.t_th, TW = st.t_tw;
+  const unsigned T = (unsigned)(st.t_nb * TH * TW), total = T * (unsigned)cv;
+  const unsigned i = block * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned tile = i / (unsigned)cv;
+  const int cq = (int)(i - tile * (unsigned)cv);
+  const unsigned trow = tile / (unsigned)TW;
+  const int tj = (int)(tile - trow * (unsigned)TW);
+  const int img = (int)(trow / (unsigned)TH);
+  const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
+  const float* x = st.t_src;
+  VT t[6][6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const int iw = 4 * tj - 1 + b;
+    VT col[6], o[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int ih = 4 * ti - 1 + a;
+      col[a] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W_)
+                   ? *reinterpret_cast<const VT*>(x + (((long long)img * H + ih) * W_ + iw) * C + cq)
+                   : vzero<VT>();
+    }
+    bt6(col, o);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][b] = o[a];
+  }
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(st.t_dst, st.t_dst_bytes);
+  const unsigned off0 = (tile * (unsigned)cv + (unsigned)cq) * 4u, ps = total * 4u;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    VT o[6];
+    bt6(t[a], o);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) buf_store1_sc1(rd, off0 + (unsigned)(6 * a + b) * ps, o[b]);
+  }
+}
+
+// One block of the output transform (+ folded BN scale / shift, ReLU), write-through stores.
+__device__ __forceinline__ void chain_wino4_output(const ChainStage& st, unsigned block) {
+  typedef float VT;
+  const int N = st.t_c, nv = N, OH = st.t_h, OW = st.t_w, TH = st.t_th, TW = st.t_tw, ldy = st.t_ldy;
+  const unsigned T = (unsigned)(st.t_nb * TH * TW), total = T * (unsigned)nv;
+  const unsigned i = block * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned tile = i / (unsigned)nv;
+  const int nq = (int)(i - tile * (unsigned)nv);
+  const unsigned trow = tile / (unsigned)TW;
+  const int tj = (int)(tile - trow * (unsigned)TW);
+  const int img = (int)(trow / (unsigned)TH);
+  const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
+  const VT* src = reinterpret_cast<const VT*>(st.t_src) + tile * (unsigned)nv + nq;
+  const size_t ps = total;
+  VT t[4][6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    VT col[6], o[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) col[a] = src[(size_t)(6 * a + b) * ps];
+    at6(col, o);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) t[a][b] = o[a];
+  }
+  VT sc = 1.f, sh = 0.f;
+  if (st.t_scale) sc = *reinterpret_cast<const VT*>(st.t_scale + nq);
+  if (st.t_shift) sh = *reinterpret_cast<const VT*>(st.t_shift + nq);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(st.t_dst, st.t_dst_bytes);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int oh = 4 * ti + a;
+    VT o[4];
+    at6(t[a], o);
+    if (oh >= OH) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ow = 4 * tj + b;
+      if (ow >= OW) continue;
+      VT v = st.t_scale ? o[b] * sc + sh : o[b] + sh;
+      if (st.t_act == 1) v = vmax0(v);
+      buf_store1_sc1(rd, (unsigned)((((unsigned)img * OH + oh) * OW + ow) * (unsigned)ldy + nq) * 4u, v);
+    }
+  }
+}
+
+constexpr unsigned kChainPollLimit = 4000000u;        // polls before a workgroup gives up (~1 us each: seconds, not a hang)
+
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) chain_kernel(ChainHeader* __restrict__ hdr, const ChainStage* __restrict__ stages,
+                                                         const ChainItem* __restrict__ items, unsigned* __restrict__ counters,
+                                                         const unsigned* __restrict__ need, unsigned n_items, unsigned n_counters) {
+  __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<64, 64, 0>()];
+  __shared__ unsigned s_ctl[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (;;) {
+    if (tid == 0) {
+      s_ctl[0] = __hip_atomic_fetch_add(&hdr->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ctl[1] = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned idx = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+    const unsigned err = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    __syncthreads();
+    if (idx >= n_items || err != 0u) break;
+    const ChainItem* ip = items + idx;
+    const int it_stage = __builtin_amdgcn_readfirstlane(ip->stage);
+    const int it_bx = __builtin_amdgcn_readfirstlane(ip->bx), it_by = __builtin_amdgcn_readfirstlane(ip->by), it_bz = __builtin_amdgcn_readfirstlane(ip->bz);
+    const int d0f = __builtin_amdgcn_readfirstlane(ip->d0_first), d0n = __builtin_amdgcn_readfirstlane(ip->d0_count);
+    const int d1f = __builtin_amdgcn_readfirstlane(ip->d1_first), d1n = __builtin_amdgcn_readfirstlane(ip->d1_count);
+    const int sig0 = __builtin_amdgcn_readfirstlane(ip->sig0), sig1 = __builtin_amdgcn_readfirstlane(ip->sig1);
+    // ---- wait until the blocks this item reads are complete: one counter per lane, one round trip per poll
+    if (wave == 0 && d0n + d1n > 0) {
+      const int ci = lane < d0n ? d0f + lane : (lane < d0n + d1n ? d1f + (lane - d0n) : -1);
+      const unsigned want = ci >= 0 ? need[ci] : 0u;
+      unsigned polls = 0;
+      for (;;) {
+        const unsigned have = ci >= 0 ? __hip_atomic_load(counters + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__all(have >= want)) break;
+        if (++polls > kChainPollLimit || __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (lane == 0) __hip_atomic_store(&hdr->error, idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // compiler-only: the item's loads stay below the poll
+    const ChainStage& st = stages[it_stage];
+    const int type = __builtin_amdgcn_readfirstlane(st.type);
+    if (type == 0) {
+      GemmArgs g = st.g;
+      conv_igemm_body<64, 64, 0, false, 4, true>(g, lds, (unsigned)it_bx, (unsigned)it_by, (unsigned)it_bz, 0u);
+    } else if (type == 1) {
+      chain_wino4_input(st, (unsigned)it_bx);
+    } else {
+      chain_wino4_output(st, (unsigned)it_bx);
+    }
+    // ---- publish: every store of this workgroup has left (write-through), then the counters move
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (sig0 >= 0) __hip_atomic_fetch_add(counters + sig0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sig1 >= 0) __hip_atomic_fetch_add(counters + sig1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- the last workgroup to leave restores the initial state (replay), keeping the first error for the host
+  if (tid == 0) s_ctl[2] = __hip_atomic_fetch_add(&hdr->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_ctl[2] != 0u) {
+    for (unsigned i = tid; i < n_counters; i += NTHREADS) __hip_atomic_store(counters + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      const unsigned e = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0u && hdr->last_error == 0u) hdr->last_error = e;
+      hdr->runs += 1u;
+      __hip_atomic_store(&hdr->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef RADNET_DIAG_STAMPS
@@ -1650,3 +1869,349 @@ extern "C" int radnet_wgrad_batched(radnet_ctx* ctx, const float* a, const float
   return run_wgrad(ctx, &d, batch, (long long)m * k, (long long)m * n, (long long)k * n);
 }
 
+// ---- host side: radnet_op[] -> stages, items, counters ----------------------------------------------------------------
+struct radnet_chain {
+  ChainHeader* d_hdr = nullptr;
+  ChainStage* d_stages = nullptr;
+  ChainItem* d_items = nullptr;
+  unsigned* d_counters = nullptr;
+  unsigned* d_need = nullptr;
+  int* d_units = nullptr;
+  float* d_slabs = nullptr;
+  unsigned n_items = 0, n_counters = 0, n_stages = 0;
+  int grid = 0;
+  double flops = 0.0;            // executed by the matrix cores
+  double flops_algorithmic = 0.0;   // 2 M N K of the layers as direct convolutions (Winograd layers credited 9 C per output)
+};
+
+namespace {
+
+// where a stage's output can be waited for
+struct ChainOut {
+  enum Kind { ROWS64, TILES64, TILEROWS } kind = ROWS64;
+  int first = 0, count = 0;       // its counters
+  int h = 0, w = 0, th = 0, tw = 0;   // TILEROWS: output geometry (pixels, tiles)
+};
+
+int chain_conv_args(radnet_ctx* ctx, const radnet_conv_desc* d, GemmArgs& g) {
+  if (!d->x || !d->w || !d->y) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: conv with a null tensor");
+  g = GemmArgs{};
+  g.x = d->x; g.w = d->w; g.y = d->y;
+  g.scale = d->scale; g.shift = d->shift; g.addend = d->addend;
+  g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow;
+  g.KW = d->kw; g.npos = d->kh * d->kw; g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
+  g.M = d->nb * d->oh * d->ow; g.N = d->n; g.K = g.npos * d->c;
+  g.ldw = d->ldw; g.ldy = d->ldy; g.ld_add = d->ld_add;
+  g.act = d->act; g.act_cols = d->act_cols;
+  g.OHOW = d->oh * d->ow;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M >= (1 << 20) || (g.ldw & 3) || (g.N & 3) || (g.C % BK) != 0 || g.npos > 32)
+    RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: conv M=%d N=%d K=%d C=%d taps=%d cannot run as chain items", g.M, g.N, g.K, g.C, g.npos);
+  if (((uintptr_t)g.x & 15) || ((uintptr_t)g.w & 15)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: x / w must be 16-byte aligned");
+  g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
+  g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+  const uint64_t xb = (uint64_t)d->nb * g.H * g.W * g.C * 4ull, wb = (uint64_t)g.K * g.ldw * 4ull;
+  const uint64_t halo = ((uint64_t)g.pad_t * g.W + g.pad_l) * g.C * 4ull;
+  const uint64_t ld_max = (uint64_t)std::max(g.ldy, g.addend ? g.ld_add : 0);
+  if (xb + halo >= (1ull << 31) || wb >= (1ull << 31) || (uint64_t)g.M * ld_max * 4ull >= (1ull << 31))
+    RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: tensor larger than 2 GiB");
+  if (g.ldy < g.N || (g.addend && g.ld_add < g.N)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: row pitch smaller than n=%d", g.N);
+  g.x_bytes = (unsigned)xb;
+  g.w_bytes = (unsigned)wb;
+  g.y_bytes = (unsigned)(((uint64_t)(g.M - 1) * g.ldy + g.N) * 4ull);
+  g.add_bytes = g.addend ? (unsigned)(((uint64_t)(g.M - 1) * g.ld_add + g.N) * 4ull) : 0u;
+  return RADNET_OK;
+}
+
+}  // namespace
+
+extern "C" void radnet_chain_destroy(radnet_chain* ch) {
+  if (!ch) return;
+  for (void* p : {(void*)ch->d_hdr, (void*)ch->d_stages, (void*)ch->d_items, (void*)ch->d_counters, (void*)ch->d_need, (void*)ch->d_units, (void*)ch->d_slabs})
+    if (p) (void)hipFree(p);
+  delete ch;
+}
+
+extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out) {
+  if (!ctx || !ops || n_ops <= 0 || !out) return RADNET_ERR_ARG;
+  *out = nullptr;
+  const int grid = workgroups > 0 ? workgroups : 2 * kNumCU;
+  std::vector<ChainStage> stages;
+  std::vector<ChainOut> outs;                   // per stage
+  std::vector<ChainItem> items;
+  std::vector<unsigned> need;                   // per counter
+  std::vector<int> units;                       // all K-split unit tables, 8 ints per unit
+  std::vector<size_t> unit_base;                // per stage: first int of its table (or ~0)
+  std::vector<size_t> slab_base, slab_floats;   // per stage (floats)
+  std::map<const void*, int> producer;          // pixel tensor -> stage that writes it
+  size_t slabs_total = 0;
+  double flops = 0.0, flops_alg = 0.0;
+
+  auto new_counters = [&](int n, unsigned want) {
+    const int first = (int)need.size();
+    need.insert(need.end(), (size_t)n, want);
+    return first;
+  };
+  // counters of `p` that cover rows [r0, r1] of the pixel tensor it writes -> (first, count)
+  auto rows_dep = [&](int p, int r0, int r1, int& first, int& count) {
+    const ChainOut& o = outs[p];
+    if (o.kind == ChainOut::ROWS64) {
+      first = o.first + r0 / 64;
+      count = r1 / 64 - r0 / 64 + 1;
+    } else {                                    // TILEROWS: one counter per (image, tile row)
+      const int y0 = r0 / o.w, y1 = r1 / o.w;   // global pixel row = image * h + oh
+      const int t0 = (y0 / o.h) * o.th + (y0 % o.h) / 4, t1 = (y1 / o.h) * o.th + (y1 % o.h) / 4;
+      first = o.first + t0;
+      count = t1 - t0 + 1;
+    }
+  };
+  auto push_stage = [&](const ChainStage& st, const ChainOut& o) {
+    stages.push_back(st);
+    outs.push_back(o);
+    unit_base.push_back(~(size_t)0);
+    slab_base.push_back(0);
+    slab_floats.push_back(0);
+    return (int)stages.size() - 1;
+  };
+  // items of one conv / batched-GEMM stage; dep(tm, first, count) gives the counters tile row tm waits for
+  auto emit_gemm = [&](int si, int batch, int dep_stage_main, int dep_stage_add, bool batched_dep) -> int {
+    GemmArgs& g = stages[si].g;
+    const int Mt = radnet_cdiv(g.M, 64), Nt = radnet_cdiv(g.N, 64), nk = radnet_cdiv(g.K, BK);
+    int S = 1;
+    if (batch <= 1) {
+      const long long tiles = (long long)Mt * Nt;
+      if (tiles < 384) S = (int)std::min<long long>(std::max(nk / 4, 1), (512 + tiles - 1) / tiles);
+      const int kt = radnet_cdiv(nk, S);
+      S = radnet_cdiv(nk, kt);
+    }
+    const int kt = radnet_cdiv(nk, S);
+    ChainOut& o = outs[si];
+    o.kind = batch > 1 ? ChainOut::TILES64 : ChainOut::ROWS64;
+    o.count = Mt;
+    o.first = new_counters(Mt, (unsigned)(Nt * S * (batch > 1 ? batch : 1)));
+    int split_counters = -1;
+    if (S > 1) {
+      unit_base[si] = units.size();
+      slab_base[si] = slabs_total;
+      slab_floats[si] = (size_t)Mt * Nt * S * 4096;
+      slabs_total += slab_floats[si];
+      split_counters = new_counters(Mt * Nt, 0u);      // arrival counters of the in-launch reduction (never polled)
+    }
+    for (int tm = 0; tm < Mt; ++tm) {
+      int d0f = 0, d0n = 0, d1f = 0, d1n = 0;
+      if (batched_dep) {                        // batched Winograd GEMM: tile block tm of the transformed operand
+        d0f = outs[dep_stage_main].first + tm;
+        d0n = 1;
+      } else {
+        if (dep_stage_main >= 0) {
+          // rows of the producer this tile's windows touch
+          int r0 = INT32_MAX, r1 = -1;
+          for (int m = tm * 64; m < std::min(g.M, tm * 64 + 64); ++m) {
+            const int img = m / g.OHOW, rem = m % g.OHOW, oh = rem / g.OW, ow = rem % g.OW;
+            const int ih0 = std::max(oh * g.stride - g.pad_t, 0), iw0 = std::max(ow * g.stride - g.pad_l, 0);
+            const int ih1 = std::min(oh * g.stride - g.pad_t + (g.npos / g.KW) - 1, g.H - 1), iw1 = std::min(ow * g.stride - g.pad_l + g.KW - 1, g.W - 1);
+            r0 = std::min(r0, (img * g.H + ih0) * g.W + iw0);
+            r1 = std::max(r1, (img * g.H + ih1) * g.W + iw1);
+          }
+          rows_dep(dep_stage_main, r0, r1, d0f, d0n);
+        }
+        if (dep_stage_add >= 0) rows_dep(dep_stage_add, tm * 64, std::min(g.M, tm * 64 + 64) - 1, d1f, d1n);
+      }
+      if (d0n + d1n > 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: an item would wait for %d blocks (64 at most)", d0n + d1n);
+      for (int bz = 0; bz < (batch > 1 ? batch : 1); ++bz)
+        for (int tn = 0; tn < Nt; ++tn)
+          for (int s = 0; s < S; ++s) {
+            ChainItem it{};
+            it.stage = si;
+            it.d0_first = d0f; it.d0_count = d0n; it.d1_first = d1f; it.d1_count = d1n;
+            it.sig0 = o.first + tm; it.sig1 = -1;
+            if (S > 1) {
+              const int tile = tn * Mt + tm;
+              const int u[8] = {tm, tn, s * kt, std::min(nk, (s + 1) * kt), tile * S + s, tile * S, S, tile};
+              it.bx = (int)((units.size() - unit_base[si]) / 8);
+              units.insert(units.end(), u, u + 8);
+            } else {
+              it.bx = tm; it.by = tn; it.bz = bz;
+            }
+            items.push_back(it);
+          }
+    }
+    if (S > 1) g.counters = reinterpret_cast<unsigned*>((uintptr_t)split_counters);      // index for now, pointer once allocated
+    return RADNET_OK;
+  };
+
+  for (int k = 0; k < n_ops; ++k) {
+    const radnet_op& op = ops[k];
+    if (op.kind == RADNET_OP_NOP) continue;
+    if (op.kind == RADNET_OP_CONV_FWD) {
+      ChainStage st{};
+      st.type = 0;
+      int rc = chain_conv_args(ctx, &op.conv, st.g);
+      if (rc != RADNET_OK) return rc;
+      const int si = push_stage(st, ChainOut{});
+      auto pm = producer.find(op.conv.x), pa = op.conv.addend ? producer.find(op.conv.addend) : producer.end();
+      rc = emit_gemm(si, 1, pm != producer.end() ? pm->second : -1, pa != producer.end() ? pa->second : -1, false);
+      if (rc != RADNET_OK) return rc;
+      producer[op.conv.y] = si;
+      flops += 2.0 * stages[si].g.M * stages[si].g.N * stages[si].g.K;
+      flops_alg += 2.0 * stages[si].g.M * stages[si].g.N * stages[si].g.K;
+    } else if (op.kind == RADNET_OP_WINO && op.i[8] == 4) {
+      const float* x = (const float*)op.p[0];
+      float* V = (float*)op.p[1];
+      const float* U = (const float*)op.p[2];
+      float* Mw = (float*)op.p[3];
+      const int nb = op.i[0], h = op.i[1], w = op.i[2], c = op.i[3], n = op.i[4], T = op.i[5], act = op.i[6], ldy = op.i[7];
+      const int th = (h + 3) / 4, tw = (w + 3) / 4;
+      if (T != nb * th * tw || (c & 63) || (n & 63) || !(256 % c == 0 || c % 256 == 0) || !(256 % n == 0 || n % 256 == 0))
+        RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: Winograd layer c=%d n=%d tiles=%d", c, n, T);
+      if ((uint64_t)36 * T * std::max(c, n) * 4ull >= (1ull << 32) || (uint64_t)nb * h * w * ldy * 4ull >= (1ull << 32))
+        RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: Winograd operand larger than 4 GiB");
+      auto pm = producer.find(x);
+      const int dep_x = pm != producer.end() ? pm->second : -1;
+      // (1) input transform: blocks of 256 units (tile, 2 channels); counters per 64 tiles
+      ChainStage s1{};
+      s1.type = 1;
+      s1.t_src = x; s1.t_dst = V; s1.t_nb = nb; s1.t_h = h; s1.t_w = w; s1.t_c = c; s1.t_th = th; s1.t_tw = tw;
+      s1.t_dst_bytes = (unsigned)((uint64_t)36 * T * c * 4ull);
+      ChainOut o1;
+      o1.kind = ChainOut::TILES64;
+      o1.count = radnet_cdiv(T, 64);
+      const int cv = c;                          // units per tile: one per channel (chain_wino4_input)
+      const int n_blk1 = radnet_cdiv((long long)T * cv, 256);
+      const int si1 = push_stage(s1, o1);
+      outs[si1].first = new_counters(o1.count, 0u);
+      for (int b = 0; b < n_blk1; ++b) {
+        const int t0 = (int)(((long long)b * 256) / cv), t1 = (int)(std::min<long long>((long long)b * 256 + 255, (long long)T * cv - 1) / cv);
+        ChainItem it{};
+        it.stage = si1; it.bx = b;
+        if (dep_x >= 0) {
+          int r0 = INT32_MAX, r1 = -1;
+          for (int t = t0; t <= t1; ++t) {
+            const int img = t / (th * tw), ti = (t / tw) % th, tj = t % tw;
+            const int ih0 = std::max(4 * ti - 1, 0), ih1 = std::min(4 * ti + 4, h - 1), iw0 = std::max(4 * tj - 1, 0), iw1 = std::min(4 * tj + 4, w - 1);
+            r0 = std::min(r0, (img * h + ih0) * w + iw0);
+            r1 = std::max(r1, (img * h + ih1) * w + iw1);
+          }
+          rows_dep(dep_x, r0, r1, it.d0_first, it.d0_count);
+          if (it.d0_count > 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block would wait for %d blocks", it.d0_count);
+        }
+        it.sig0 = outs[si1].first + t0 / 64;
+        it.sig1 = t1 / 64 != t0 / 64 ? outs[si1].first + t1 / 64 : -1;
+        if (t1 / 64 > t0 / 64 + 1) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile blocks");
+        need[(size_t)it.sig0] += 1u;
+        if (it.sig1 >= 0) need[(size_t)it.sig1] += 1u;
+        items.push_back(it);
+      }
+      // (2) 36 GEMMs [T x c] . [c x n] as one batched stage
+      ChainStage s2{};
+      s2.type = 0;
+      GemmArgs& g = s2.g;
+      g.x = V; g.w = U; g.y = Mw;
+      g.H = 1; g.W = T; g.C = c; g.OH = 1; g.OW = T;
+      g.KW = 1; g.npos = 1; g.stride = 1;
+      g.M = T; g.N = n; g.K = c;
+      g.ldw = n; g.ldy = n;
+      g.OHOW = T;
+      g.batch = 36;
+      g.x_bstride = (long long)T * c; g.w_bstride = (long long)c * n; g.y_bstride = (long long)T * n;
+      g.magic_ohow = radnet_div_magic((uint32_t)g.OHOW);
+      g.magic_ow = radnet_div_magic((uint32_t)g.OW);
+      g.x_bytes = (unsigned)((uint64_t)T * c * 4ull);
+      g.w_bytes = (unsigned)((uint64_t)c * n * 4ull);
+      g.y_bytes = (unsigned)(((uint64_t)(T - 1) * n + n) * 4ull);
+      const int si2 = push_stage(s2, ChainOut{});
+      int rc = emit_gemm(si2, 36, si1, -1, true);
+      if (rc != RADNET_OK) return rc;
+      // (3) output transform: counters per (image, tile row)
+      ChainStage s3{};
+      s3.type = 2;
+      s3.t_src = Mw; s3.t_dst = (float*)op.p[6]; s3.t_scale = (const float*)op.p[4]; s3.t_shift = (const float*)op.p[5];
+      s3.t_nb = nb; s3.t_h = h; s3.t_w = w; s3.t_c = n; s3.t_th = th; s3.t_tw = tw; s3.t_act = act; s3.t_ldy = ldy;
+      s3.t_dst_bytes = (unsigned)((uint64_t)nb * h * w * ldy * 4ull);
+      ChainOut o3;
+      o3.kind = ChainOut::TILEROWS;
+      o3.count = nb * th;
+      o3.h = h; o3.w = w; o3.th = th; o3.tw = tw;
+      const int si3 = push_stage(s3, o3);
+      outs[si3].first = new_counters(o3.count, 0u);
+      const int nv = n;
+      const int n_blk3 = radnet_cdiv((long long)T * nv, 256);
+      for (int b = 0; b < n_blk3; ++b) {
+        const int t0 = (int)(((long long)b * 256) / nv), t1 = (int)(std::min<long long>((long long)b * 256 + 255, (long long)T * nv - 1) / nv);
+        ChainItem it{};
+        it.stage = si3; it.bx = b;
+        it.d0_first = outs[si2].first + t0 / 64;
+        it.d0_count = t1 / 64 - t0 / 64 + 1;
+        const int row0 = t0 / tw, row1 = t1 / tw;         // (image * th + tile row)
+        if (row1 > row0 + 1) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile rows");
+        it.sig0 = outs[si3].first + row0;
+        it.sig1 = row1 != row0 ? outs[si3].first + row1 : -1;
+        need[(size_t)it.sig0] += 1u;
+        if (it.sig1 >= 0) need[(size_t)it.sig1] += 1u;
+        items.push_back(it);
+      }
+      producer[op.p[6]] = si3;
+      flops += 2.0 * 36.0 * T * (double)n * c;
+      flops_alg += 2.0 * nb * h * w * (double)n * 9.0 * c;
+    } else {
+      RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: op kind %d at position %d cannot run as chain items", op.kind, k);
+    }
+  }
+  if (items.empty()) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: empty program");
+
+  radnet_chain* ch = new radnet_chain();
+  ch->grid = grid;
+  ch->n_items = (unsigned)items.size();
+  ch->n_counters = (unsigned)need.size();
+  ch->n_stages = (unsigned)stages.size();
+  ch->flops = flops;
+  ch->flops_algorithmic = flops_alg;
+  auto fail = [&](const char* what) {
+    radnet_chain_destroy(ch);
+    snprintf(ctx->err, sizeof(ctx->err), "chain: %s", what);
+    return RADNET_ERR_HIP;
+  };
+  if (hipMalloc((void**)&ch->d_hdr, sizeof(ChainHeader)) != hipSuccess || hipMemset(ch->d_hdr, 0, sizeof(ChainHeader)) != hipSuccess) return fail("header");
+  if (hipMalloc((void**)&ch->d_counters, need.size() * 4) != hipSuccess || hipMemset(ch->d_counters, 0, need.size() * 4) != hipSuccess) return fail("counters");
+  if (hipMalloc((void**)&ch->d_need, need.size() * 4) != hipSuccess || hipMemcpy(ch->d_need, need.data(), need.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("need");
+  if (!units.empty() && (hipMalloc((void**)&ch->d_units, units.size() * 4) != hipSuccess || hipMemcpy(ch->d_units, units.data(), units.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) return fail("units");
+  if (slabs_total && hipMalloc((void**)&ch->d_slabs, slabs_total * 4) != hipSuccess) return fail("slabs");
+  for (size_t s = 0; s < stages.size(); ++s) {
+    if (unit_base[s] == ~(size_t)0) continue;
+    GemmArgs& g = stages[s].g;
+    g.units = ch->d_units + unit_base[s];
+    g.partial = ch->d_slabs + slab_base[s];
+    g.counters = ch->d_counters + (uintptr_t)g.counters;
+  }
+  if (hipMalloc((void**)&ch->d_stages, stages.size() * sizeof(ChainStage)) != hipSuccess ||
+      hipMemcpy(ch->d_stages, stages.data(), stages.size() * sizeof(ChainStage), hipMemcpyHostToDevice) != hipSuccess) return fail("stages");
+  if (hipMalloc((void**)&ch->d_items, items.size() * sizeof(ChainItem)) != hipSuccess ||
+      hipMemcpy(ch->d_items, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice) != hipSuccess) return fail("items");
+  *out = ch;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_chain_run(radnet_ctx* ctx, radnet_chain* ch) {
+  if (!ctx || !ch) return RADNET_ERR_ARG;
+  radnet_timing_arm(ctx);
+  RADNET_LAUNCH(chain_kernel, dim3(ch->grid), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, ch->d_hdr, ch->d_stages, ch->d_items, ch->d_counters,
+                ch->d_need, ch->n_items, ch->n_counters);
+  RADNET_CHECK_LAUNCH(ctx, "chain");
+  radnet_timing_end_armed(ctx, 0, ch->flops_algorithmic);
+  return RADNET_OK;
+}
+
+// Synchronises the context's stream.  last_error: 0, or 1 + the index of the first item that gave up waiting (sticky).
+extern "C" int radnet_chain_status(radnet_ctx* ctx, radnet_chain* ch, int32_t* last_error, int32_t* runs, int32_t* n_items, int32_t* n_stages,
+                                   double* flops_executed, double* flops_algorithmic) {
+  if (!ctx || !ch) return RADNET_ERR_ARG;
+  RADNET_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ChainHeader h;
+  RADNET_CHECK_HIP(ctx, hipMemcpy(&h, ch->d_hdr, sizeof(h), hipMemcpyDeviceToHost));
+  if (last_error) *last_error = (int32_t)h.last_error;
+  if (runs) *runs = (int32_t)h.runs;
+  if (n_items) *n_items = (int32_t)ch->n_items;
+  if (n_stages) *n_stages = (int32_t)ch->n_stages;
+  if (flops_executed) *flops_executed = ch->flops;
+  if (flops_algorithmic) *flops_algorithmic = ch->flops_algorithmic;
+  return RADNET_OK;
+}

@@ -99,6 +99,7 @@ extern "C" int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t
       case RADNET_OP_RELU_MASK:
         rc = radnet_relu_mask(ctx, (float*)const_cast<void*>(o.p[0]), (const float*)o.p[1], ((int64_t)o.i[1] << 32) | (uint32_t)o.i[0]);
         break;
+      case RADNET_OP_CHAIN: rc = radnet_chain_run(ctx, (radnet_chain*)const_cast<void*>(o.p[0])); break;
       case RADNET_OP_ROI_BWD:
         rc = radnet_roi_resize_bwd(ctx, (const float*)o.p[0], o.i[0], o.i[1], o.i[2], (const float*)o.p[1], o.i[3], o.i[4], (float*)o.p[2]);
         break;

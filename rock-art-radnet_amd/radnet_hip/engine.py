@@ -157,6 +157,9 @@ class FasterRCNNEngine:
         # classifier tail (avg-pool, dense heads, detector losses) as one launch instead of three
         self.fuse_tail = os.environ.get("RADNET_NO_TAIL_FUSION", "0") != "1"
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
+        # frozen base forward (stages 2-4) as one persistent launch of `chain_wgs` workgroups (0: two per CU); DESIGN.md 4
+        self.use_chain = os.environ.get("RADNET_CHAIN", "0") == "1"
+        self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "0"))
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
@@ -483,13 +486,43 @@ class FasterRCNNEngine:
                 d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
                 cur, h, w = out, oh, ow
         plan = dict(ops=ops, x=x, F=cur, fh=h, fw=w, keep=keep, nb=nb)
+        if self.use_chain:
+            self._chain_ops(plan, first=2)               # conv1 (4-channel stem) and the max-pool stay launches of their own
         self._plans[key] = plan
         return plan
+
+    def _chain_ops(self, plan, first=0):
+        """Replace plan['ops'][first:] by ONE persistent launch (radnet_chain_build, include/radnet_hip.h): the same
+        convs / Winograd layers as work items with arrival counters instead of ~50 dependent launches.  Falls back to the
+        launch list (and says so once) when the library refuses an op."""
+        sub = plan["ops"][first:]
+        arr = self._compile(sub)
+        h = C.c_void_p()
+        rc = self.lib.radnet_chain_build(self.ctx.h, C.cast(arr, C.c_void_p), len(sub), self.chain_wgs, C.byref(h))
+        if rc != 0:
+            if not getattr(self, "_chain_warned", False):
+                self._chain_warned = True
+                import sys
+                sys.stderr.write("radnet: chain refused (%s); the layer program runs launch by launch\n" % self.lib.radnet_last_error(self.ctx.h).decode())
+            return
+        plan["chain"] = h
+        plan["chain_sub"] = sub                           # keeps the descriptors (and the compiled array) alive
+        plan["ops"] = plan["ops"][:first] + [("chain", h)]
+
+    def chain_status(self, plan):
+        """(last_error, runs, items, stages, executed flops, algorithmic flops) of a plan's chain; synchronises the lane."""
+        e, r, n, st = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        fe, fa = C.c_double(), C.c_double()
+        self.ctx.check(self.lib.radnet_chain_status(self.ctx.h, plan["chain"], C.byref(e), C.byref(r), C.byref(n), C.byref(st), C.byref(fe), C.byref(fa)), "chain_status")
+        return e.value, r.value, n.value, st.value, fe.value, fa.value
 
     def _evict_plan(self, key, plan):
         """A plan leaves the cache: nothing may still be reading its buffers (lanes run ahead of the host), and the
         hipGraphs recorded from its launch lists go with it."""
         torch.cuda.synchronize(self.dev)
+        if plan.get("chain") is not None:
+            self.lib.radnet_chain_destroy(plan["chain"])
+            plan["chain"] = None
         lists = set()
         for v in plan.values():
             if isinstance(v, list):
@@ -635,6 +668,9 @@ class FasterRCNNEngine:
                 o.kind = L.OP_RELU_MASK
                 o.p[0], o.p[1] = ptr(g), ptr(act)
                 o.i[0], o.i[1] = C.c_int32(n & 0xFFFFFFFF).value, int(n) >> 32
+            elif kind == "chain":
+                o.kind = L.OP_CHAIN
+                o.p[0] = p.value
             elif kind == "roi_bwd":
                 dy, hh, ww, c, rois, r, ps, dF = p
                 o.kind = L.OP_ROI_BWD

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
 
 # ---- layer programs and composed entry points (include/radnet_hip.h, csrc/program.hip) --------------------------------
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_MAXPOOL, OP_COLSUM, OP_WINO, OP_WINO_REUSE, OP_WINO_WGRAD, OP_SCATTER, OP_FILL0, \
-    OP_RELU_MASK, OP_ROI_BWD, OP_CONV_BWD = range(1, 14)
+    OP_RELU_MASK, OP_ROI_BWD, OP_CONV_BWD, OP_CHAIN = range(1, 15)
 OP_NOP = 0
 
 
@@ -207,6 +207,10 @@ def load_library():
         "radnet_comm_destroy": (C.c_int, [vp]),
         "radnet_allreduce_grads": (C.c_int, [vp, vp, i64]),
         "radnet_comm_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "radnet_chain_build": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "radnet_chain_run": (C.c_int, [vp, vp]),
+        "radnet_chain_status": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
+        "radnet_chain_destroy": (None, [vp]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
     }
     for name, (res, args) in sig.items():
