@@ -366,6 +366,18 @@ int radnet_chain_run(radnet_ctx* ctx, radnet_chain* chain);
 int radnet_chain_status(radnet_ctx* ctx, radnet_chain* chain, int32_t* last_error, int32_t* runs, int32_t* n_items, int32_t* n_stages,
                         double* flops_executed, double* flops_algorithmic);
 void radnet_chain_destroy(radnet_chain* chain);
+/* Diagnosis while a chain launch runs (uses a stream of its own): out[0..7] = {next item, workgroups gone, error, first
+ * error, runs, ...}; with item >= 0, out[8..19] = its record {stage, bx, by, bz, dep0 first, dep0 count, dep1 first, dep1 count,
+ * signal 0, signal 1, ..} and out[20 + 2k], out[21 + 2k] = current value / expected value of the k-th counter it waits for.
+ * Returns the number of such pairs (or a negative error); out_words >= 148. */
+int radnet_chain_peek(radnet_chain* chain, int32_t item, uint32_t* out, int32_t out_words);
+/* Host-only (no device, no context): plans the work-item list of `ops` as radnet_chain_build would and checks that it can
+ * run in list order -- every item finds its input blocks completed by earlier items, every counter reaches exactly the
+ * count its waiters expect -- which is what makes the launch deadlock-free for any number of workgroups.  first_bad_item:
+ * -1, or the offending item (n_items: a counter that never reaches its count).  The pointers in `ops` are used as
+ * identities only.  radnet_chain_build runs the same check and refuses a list that fails it. */
+int radnet_chain_check(const radnet_op* ops, int32_t n_ops, int32_t* n_items, int32_t* n_stages, int32_t* n_counters, int32_t* first_bad_item,
+                       int32_t* bad_counter, char* err, int32_t err_len);
 
 /* model_rpn.predict (RADNet.py:552; train.py:291): nn_base program, then rpn_layer program (outputs where the programs'
  * descriptors point: the fused head matrix [fh*fw][ld] with the sigmoid scores in columns [0,A), regressions in [A,5A)). */

@@ -1535,7 +1535,7 @@ __device__ __forceinline__ void chain_wino4_output(const ChainStage& st, unsigne
   }
 }
 
-constexpr unsigned kChainPollLimit = 4000000u;        // polls before a workgroup gives up (~1 us each: seconds, not a hang)
+constexpr unsigned long long kChainGiveUpTicks = 100000000ull;      // 1 s of the 100 MHz real-time counter: a workgroup gives up waiting
 
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) chain_kernel(ChainHeader* __restrict__ hdr, const ChainStage* __restrict__ stages,
                                                          const ChainItem* __restrict__ items, unsigned* __restrict__ counters,
@@ -1563,15 +1563,19 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4
     if (wave == 0 && d0n + d1n > 0) {
       const int ci = lane < d0n ? d0f + lane : (lane < d0n + d1n ? d1f + (lane - d0n) : -1);
       const unsigned want = ci >= 0 ? need[ci] : 0u;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, constant
       unsigned polls = 0;
       for (;;) {
         const unsigned have = ci >= 0 ? __hip_atomic_load(counters + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (__all(have >= want)) break;
-        if (++polls > kChainPollLimit || __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          if (lane == 0) __hip_atomic_store(&hdr->error, idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
+        if ((++polls & 63u) == 0u) {             // now and then: has somebody given up / have we waited kChainGiveUpTicks
+          const bool late = __builtin_amdgcn_s_memrealtime() - t0 > kChainGiveUpTicks;
+          if (late || __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (late && lane == 0) __hip_atomic_store(&hdr->error, idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(8);
       }
     }
     __syncthreads();
@@ -1880,6 +1884,8 @@ struct radnet_chain {
   float* d_slabs = nullptr;
   unsigned n_items = 0, n_counters = 0, n_stages = 0;
   int grid = 0;
+  std::vector<ChainItem> h_items;       // host copies for radnet_chain_peek / diagnosis
+  std::vector<unsigned> h_need;
   double flops = 0.0;            // executed by the matrix cores
   double flops_algorithmic = 0.0;   // 2 M N K of the layers as direct convolutions (Winograd layers credited 9 C per output)
 };
@@ -1893,7 +1899,8 @@ struct ChainOut {
   int h = 0, w = 0, th = 0, tw = 0;   // TILEROWS: output geometry (pixels, tiles)
 };
 
-int chain_conv_args(radnet_ctx* ctx, const radnet_conv_desc* d, GemmArgs& g) {
+template <typename E>
+int chain_conv_args(E* ctx, const radnet_conv_desc* d, GemmArgs& g) {
   if (!d->x || !d->w || !d->y) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: conv with a null tensor");
   g = GemmArgs{};
   g.x = d->x; g.w = d->w; g.y = d->y;
@@ -1931,20 +1938,34 @@ extern "C" void radnet_chain_destroy(radnet_chain* ch) {
   delete ch;
 }
 
-extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out) {
-  if (!ctx || !ops || n_ops <= 0 || !out) return RADNET_ERR_ARG;
-  *out = nullptr;
-  const int grid = workgroups > 0 ? workgroups : 2 * kNumCU;
+struct ChainPlan {
   std::vector<ChainStage> stages;
-  std::vector<ChainOut> outs;                   // per stage
   std::vector<ChainItem> items;
   std::vector<unsigned> need;                   // per counter
   std::vector<int> units;                       // all K-split unit tables, 8 ints per unit
   std::vector<size_t> unit_base;                // per stage: first int of its table (or ~0)
-  std::vector<size_t> slab_base, slab_floats;   // per stage (floats)
-  std::map<const void*, int> producer;          // pixel tensor -> stage that writes it
+  std::vector<size_t> slab_base;                // per stage (floats)
   size_t slabs_total = 0;
   double flops = 0.0, flops_alg = 0.0;
+};
+struct ErrSink {                                // RADNET_FAIL needs ->err
+  char err[512];
+};
+
+// Host-only: the work-item list of a program (no device call; radnet_chain_check runs it without a GPU).
+static int chain_plan(const radnet_op* ops, int32_t n_ops, ChainPlan& pl, ErrSink& ec) {
+  std::vector<ChainStage>& stages = pl.stages;
+  std::vector<ChainOut> outs;                   // per stage
+  std::vector<ChainItem>& items = pl.items;
+  std::vector<unsigned>& need = pl.need;
+  std::vector<int>& units = pl.units;
+  std::vector<size_t>& unit_base = pl.unit_base;
+  std::vector<size_t>& slab_base = pl.slab_base;
+  std::vector<size_t> slab_floats;              // per stage (floats)
+  std::map<const void*, int> producer;          // pixel tensor -> stage that writes it
+  size_t& slabs_total = pl.slabs_total;
+  double& flops = pl.flops;
+  double& flops_alg = pl.flops_alg;
 
   auto new_counters = [&](int n, unsigned want) {
     const int first = (int)need.size();
@@ -2016,7 +2037,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
         }
         if (dep_stage_add >= 0) rows_dep(dep_stage_add, tm * 64, std::min(g.M, tm * 64 + 64) - 1, d1f, d1n);
       }
-      if (d0n + d1n > 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: an item would wait for %d blocks (64 at most)", d0n + d1n);
+      if (d0n + d1n > 64) RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: an item would wait for %d blocks (64 at most)", d0n + d1n);
       for (int bz = 0; bz < (batch > 1 ? batch : 1); ++bz)
         for (int tn = 0; tn < Nt; ++tn)
           for (int s = 0; s < S; ++s) {
@@ -2045,7 +2066,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
     if (op.kind == RADNET_OP_CONV_FWD) {
       ChainStage st{};
       st.type = 0;
-      int rc = chain_conv_args(ctx, &op.conv, st.g);
+      int rc = chain_conv_args(&ec, &op.conv, st.g);
       if (rc != RADNET_OK) return rc;
       const int si = push_stage(st, ChainOut{});
       auto pm = producer.find(op.conv.x), pa = op.conv.addend ? producer.find(op.conv.addend) : producer.end();
@@ -2062,9 +2083,9 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
       const int nb = op.i[0], h = op.i[1], w = op.i[2], c = op.i[3], n = op.i[4], T = op.i[5], act = op.i[6], ldy = op.i[7];
       const int th = (h + 3) / 4, tw = (w + 3) / 4;
       if (T != nb * th * tw || (c & 63) || (n & 63) || !(256 % c == 0 || c % 256 == 0) || !(256 % n == 0 || n % 256 == 0))
-        RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: Winograd layer c=%d n=%d tiles=%d", c, n, T);
+        RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: Winograd layer c=%d n=%d tiles=%d", c, n, T);
       if ((uint64_t)36 * T * std::max(c, n) * 4ull >= (1ull << 32) || (uint64_t)nb * h * w * ldy * 4ull >= (1ull << 32))
-        RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: Winograd operand larger than 4 GiB");
+        RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: Winograd operand larger than 4 GiB");
       auto pm = producer.find(x);
       const int dep_x = pm != producer.end() ? pm->second : -1;
       // (1) input transform: blocks of 256 units (tile, 2 channels); counters per 64 tiles
@@ -2092,11 +2113,11 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
             r1 = std::max(r1, (img * h + ih1) * w + iw1);
           }
           rows_dep(dep_x, r0, r1, it.d0_first, it.d0_count);
-          if (it.d0_count > 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block would wait for %d blocks", it.d0_count);
+          if (it.d0_count > 64) RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: a transform block would wait for %d blocks", it.d0_count);
         }
         it.sig0 = outs[si1].first + t0 / 64;
         it.sig1 = t1 / 64 != t0 / 64 ? outs[si1].first + t1 / 64 : -1;
-        if (t1 / 64 > t0 / 64 + 1) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile blocks");
+        if (t1 / 64 > t0 / 64 + 1) RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile blocks");
         need[(size_t)it.sig0] += 1u;
         if (it.sig1 >= 0) need[(size_t)it.sig1] += 1u;
         items.push_back(it);
@@ -2142,7 +2163,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
         it.d0_first = outs[si2].first + t0 / 64;
         it.d0_count = t1 / 64 - t0 / 64 + 1;
         const int row0 = t0 / tw, row1 = t1 / tw;         // (image * th + tile row)
-        if (row1 > row0 + 1) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile rows");
+        if (row1 > row0 + 1) RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: a transform block spans three tile rows");
         it.sig0 = outs[si3].first + row0;
         it.sig1 = row1 != row0 ? outs[si3].first + row1 : -1;
         need[(size_t)it.sig0] += 1u;
@@ -2153,10 +2174,71 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
       flops += 2.0 * 36.0 * T * (double)n * c;
       flops_alg += 2.0 * nb * h * w * (double)n * 9.0 * c;
     } else {
-      RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: op kind %d at position %d cannot run as chain items", op.kind, k);
+      RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: op kind %d at position %d cannot run as chain items", op.kind, k);
     }
   }
-  if (items.empty()) RADNET_FAIL(ctx, RADNET_ERR_ARG, "chain: empty program");
+  if (pl.items.empty()) RADNET_FAIL(&ec, RADNET_ERR_ARG, "chain: empty program");
+  return RADNET_OK;
+}
+
+// In list order, with every earlier item finished, each item must find its input blocks complete: then a single workgroup
+// can run the list, and any number of workgroups drawing from it in order cannot deadlock.  Also: every counter reaches
+// exactly its `need`.  Returns the first offending item (or -1).
+static int chain_first_unrunnable(const ChainPlan& pl, int* bad_counter) {
+  std::vector<unsigned> c(pl.need.size(), 0u);
+  for (size_t i = 0; i < pl.items.size(); ++i) {
+    const ChainItem& it = pl.items[i];
+    for (int k = 0; k < it.d0_count; ++k)
+      if (c[(size_t)it.d0_first + k] < pl.need[(size_t)it.d0_first + k]) { *bad_counter = it.d0_first + k; return (int)i; }
+    for (int k = 0; k < it.d1_count; ++k)
+      if (c[(size_t)it.d1_first + k] < pl.need[(size_t)it.d1_first + k]) { *bad_counter = it.d1_first + k; return (int)i; }
+    if (it.sig0 >= 0) c[(size_t)it.sig0] += 1u;
+    if (it.sig1 >= 0) c[(size_t)it.sig1] += 1u;
+  }
+  for (size_t k = 0; k < c.size(); ++k)
+    if (pl.need[k] != 0u && c[k] != pl.need[k]) { *bad_counter = (int)k; return (int)pl.items.size(); }
+  return -1;
+}
+
+extern "C" int radnet_chain_check(const radnet_op* ops, int32_t n_ops, int32_t* n_items, int32_t* n_stages, int32_t* n_counters, int32_t* first_bad_item,
+                                  int32_t* bad_counter, char* err, int32_t err_len) {
+  if (!ops || n_ops <= 0) return RADNET_ERR_ARG;
+  ChainPlan pl;
+  ErrSink ec{};
+  const int rc = chain_plan(ops, n_ops, pl, ec);
+  if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", ec.err);
+  if (rc != RADNET_OK) return rc;
+  int bc = -1;
+  const int bad = chain_first_unrunnable(pl, &bc);
+  if (n_items) *n_items = (int32_t)pl.items.size();
+  if (n_stages) *n_stages = (int32_t)pl.stages.size();
+  if (n_counters) *n_counters = (int32_t)pl.need.size();
+  if (first_bad_item) *first_bad_item = bad;
+  if (bad_counter) *bad_counter = bc;
+  return RADNET_OK;
+}
+
+extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out) {
+  if (!ctx || !ops || n_ops <= 0 || !out) return RADNET_ERR_ARG;
+  *out = nullptr;
+  const int grid = workgroups > 0 ? workgroups : 2 * kNumCU;
+  ChainPlan pl;
+  {
+    ErrSink ec{};
+    const int rc = chain_plan(ops, n_ops, pl, ec);
+    if (rc != RADNET_OK) RADNET_FAIL(ctx, rc, "%s", ec.err);
+    int bc = -1;
+    const int bad = chain_first_unrunnable(pl, &bc);
+    if (bad >= 0) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "chain: item %d of %d cannot run in list order (counter %d)", bad, (int)pl.items.size(), bc);
+  }
+  std::vector<ChainStage>& stages = pl.stages;
+  std::vector<ChainItem>& items = pl.items;
+  std::vector<unsigned>& need = pl.need;
+  std::vector<int>& units = pl.units;
+  std::vector<size_t>& unit_base = pl.unit_base;
+  std::vector<size_t>& slab_base = pl.slab_base;
+  const size_t slabs_total = pl.slabs_total;
+  const double flops = pl.flops, flops_alg = pl.flops_alg;
 
   radnet_chain* ch = new radnet_chain();
   ch->grid = grid;
@@ -2186,8 +2268,36 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
       hipMemcpy(ch->d_stages, stages.data(), stages.size() * sizeof(ChainStage), hipMemcpyHostToDevice) != hipSuccess) return fail("stages");
   if (hipMalloc((void**)&ch->d_items, items.size() * sizeof(ChainItem)) != hipSuccess ||
       hipMemcpy(ch->d_items, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice) != hipSuccess) return fail("items");
+  ch->h_items = items;
+  ch->h_need = need;
   *out = ch;
   return RADNET_OK;
+}
+
+// Diagnosis WHILE a chain launch is (or seems to be) running: copies the header {next item, workgroups gone, error, first
+// error, runs} and, for item `item` (>= 0), its record and the current values / expected values of the counters it waits
+// for, through a stream of its own (does not wait for the launch).  out: 8 header words, 12 item words, then up to 64
+// (have, need) pairs; returns the number of pairs.
+extern "C" int radnet_chain_peek(radnet_chain* ch, int32_t item, uint32_t* out, int32_t out_words) {
+  if (!ch || !out || out_words < 20 + 128) return RADNET_ERR_ARG;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return RADNET_ERR_HIP;
+  int pairs = 0;
+  bool ok = hipMemcpyAsync(out, ch->d_hdr, 8 * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (ok && item >= 0 && (unsigned)item < ch->n_items) {
+    const ChainItem& it = ch->h_items[(size_t)item];
+    memcpy(out + 8, &it, 12 * 4);
+    for (int r = 0; r < 2 && ok; ++r) {
+      const int f = r == 0 ? it.d0_first : it.d1_first, n = r == 0 ? it.d0_count : it.d1_count;
+      for (int k = 0; k < n && pairs < 64 && ok; ++k, ++pairs) {
+        ok = hipMemcpyAsync(out + 20 + 2 * pairs, ch->d_counters + f + k, 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        out[20 + 2 * pairs + 1] = ch->h_need[(size_t)f + k];
+      }
+    }
+  }
+  ok = ok && hipStreamSynchronize(st) == hipSuccess;
+  (void)hipStreamDestroy(st);
+  return ok ? pairs : RADNET_ERR_HIP;
 }
 
 extern "C" int radnet_chain_run(radnet_ctx* ctx, radnet_chain* ch) {

@@ -211,6 +211,8 @@ def load_library():
         "radnet_chain_run": (C.c_int, [vp, vp]),
         "radnet_chain_status": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
         "radnet_chain_destroy": (None, [vp]),
+        "radnet_chain_peek": (C.c_int, [vp, i32, C.POINTER(C.c_uint32), i32]),
+        "radnet_chain_check": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
         "radnet_scale": (C.c_int, [vp, vp, i64, f32]),
     }
     for name, (res, args) in sig.items():

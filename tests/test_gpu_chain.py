@@ -46,7 +46,7 @@ def test_chain_base_forward_equals_launch_list_and_oracle(shape):
     assert bp1.get("chain") is not None and len(bp1["ops"]) == 3           # conv1, max-pool, the chain
     F1 = e1.base_forward(bp1).cpu().numpy()
     err, runs, n_items, n_stages, fe, fa = e1.chain_status(bp1)
-    assert err == 0 and runs == 1 and n_stages == 30 + 3 * 10              # 30 direct convs + 10 Winograd layers x 3 stages
+    assert err == 0 and runs == 1 and n_stages == 32 + 3 * 10              # 32 direct convs + 10 Winograd layers x 3 stages
     assert fa > fe > 0
     check(F1, F0, 2e-5, "chain vs launch list")                            # same function, another fp32 summation order
     if shape == (300, 500):
