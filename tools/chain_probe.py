@@ -58,6 +58,9 @@ def main():
             say("prefix %3d ops: finished in < %.2f s, first error %d" % (n, time.time() - t0, out[3]))
         else:
             say("prefix %3d ops: NOT finished after 6 s: next item %d, workgroups gone %d, error %d" % (n, out[0], out[1], out[2]))
+            eng.lib.radnet_chain_peek(h, -2, out, 160)
+            say("   waves by phase (0 never ran, 1 drew an item, 2 inputs complete, 3 item computed, 4 stores drained, 5 left):", [out[20 + j] for j in range(8)],
+                "a stuck wave: phase %d item %d" % (out[28] & 255, out[28] >> 8))
             # the items around the queue head: which one waits for what
             lo = max(0, int(out[0]) - 1200)
             stuck = 0

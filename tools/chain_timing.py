@@ -40,7 +40,7 @@ def main():
     bp = eng.upload_image(img)
     F0 = eng.base_forward(bp).cpu().numpy()
     print("launch list (hipGraph replay): %.3f ms" % time_base(eng, bp))
-    for wgs in (128, 256, 384, 512, 768, 1024):
+    for wgs in (int(v) for v in os.environ.get("CHAIN_WGS_LIST", "128,256,384,512,768,1024").split(",")):
         e = FasterRCNNEngine(C)
         e.use_chain, e.chain_wgs = True, wgs
         e.set_weights(Wt)
