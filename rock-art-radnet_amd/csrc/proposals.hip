@@ -532,7 +532,9 @@ extern "C" int radnet_rpn_to_roi(radnet_ctx* ctx, const float* pred, int32_t ld_
   // examined): radix select 78 us + LDS bitonic sort of 4 096 keys 67 us against rocPRIM's 45 us for the full sort, and the
   // greedy scan itself -- 38 chunks of 64 candidates at ~5 us, three barriers and a serial resolve each -- costs the same
   // ~200 us with integer arithmetic as with fp64 (it is latency-, not arithmetic-bound).  So the full sort stays the default.
-  if (use_regr && rows < 32768 && cols < 32768 && overlap_thresh > 0.0 && getenv("RADNET_PROPOSALS_SELECT") != nullptr) {
+  const char* sel_env = getenv("RADNET_PROPOSALS_SELECT");      // read per call: the tests and tools/proposals_timing.py switch it in one process
+  const bool select_path = sel_env != nullptr && strcmp(sel_env, "1") == 0;
+  if (use_regr && rows < 32768 && cols < 32768 && overlap_thresh > 0.0 && select_path) {
     IBox* ib = reinterpret_cast<IBox*>(L.boxes);          // the fp64 box area of the workspace holds the packed boxes instead
     hipLaunchKernelGGL(decode_kernel, dim3(radnet_cdiv(n, 256)), dim3(256), 0, ctx->stream, g, (double4*)nullptr, ib, L.keys_in, (int*)nullptr);
     RADNET_CHECK_LAUNCH(ctx, "decode");

@@ -291,7 +291,11 @@ def resize_cubic(img, new_w, new_h, to_host=True, ctx=None):
             if to_host:
                 return out.cpu().numpy()
     if side is not None:
-        torch.cuda.current_stream().wait_stream(side)          # a device result made on the worker's stream: its consumer's stream waits
+        # a device result made on the worker's stream: its consumer's stream waits, and the caching allocator is told that the
+        # memory is in use there too (it was allocated under `side`; without this it could be handed out again while the
+        # consumer still reads it)
+        torch.cuda.current_stream().wait_stream(side)
+        out.record_stream(torch.cuda.current_stream())
     return out
 
 

@@ -226,11 +226,19 @@ class BackgroundFeed:
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._stop = threading.Event()
         self._feed = feed
+        try:                                   # the worker must use THIS thread's GPU (per-thread current device; ranks of a DP job)
+            from radnet_hip import runtime as _rt
+            self._device = _rt.note_owner_device()
+        except Exception:                      # no GPU stack importable: a host-only feed (resize hook given)
+            self._device = None
         self._thread = threading.Thread(target=self._work, name="radnet-feed", daemon=True)
         self._thread.start()
 
     def _work(self):
         try:
+            if self._device is not None:
+                from radnet_hip import runtime as _rt
+                _rt.bind_thread_device(self._device)
             for sample in self._feed:
                 while not self._stop.is_set():
                     try:

@@ -25,9 +25,34 @@ def default_context():
             _ctx = L.Context(torch.cuda.current_device() if torch.cuda.is_available() else 0)
         return _ctx
     if getattr(_local, "ctx", None) is None:
-        _local.stream = torch.cuda.Stream()
-        _local.ctx = L.Context(torch.cuda.current_device(), stream_handle=_local.stream.cuda_stream)
+        # The current device is per thread in HIP / torch and a new thread starts on device 0: a worker of rank r's process
+        # must follow the device its creator uses (bind_thread_device), or every rank's feed worker would put its stream,
+        # context and resize buffers on GPU 0.
+        dev = getattr(_local, "device", None)
+        if dev is None:
+            dev = _owner_device if _owner_device is not None else torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+        _local.stream = torch.cuda.Stream(device=dev)
+        _local.ctx = L.Context(dev, stream_handle=_local.stream.cuda_stream)
     return _local.ctx
+
+
+_owner_device = None
+
+
+def note_owner_device():
+    """Called on the thread that CREATES a worker (data_feed.BackgroundFeed.__init__): remembers its current device."""
+    global _owner_device
+    if torch.cuda.is_available():
+        _owner_device = torch.cuda.current_device()
+    return _owner_device
+
+
+def bind_thread_device(dev):
+    """First thing a worker thread does: make `dev` (its creator's device) its own current device."""
+    if dev is not None and torch.cuda.is_available():
+        torch.cuda.set_device(dev)
+        _local.device = dev
 
 
 def thread_stream():
@@ -36,11 +61,12 @@ def thread_stream():
 
 
 def scratch(name, nbytes):
-    """Grow-only named device scratch buffers (uint8)."""
-    t = _scratch.get(name)
+    """Grow-only named device scratch buffers (uint8), per device."""
+    key = (name, torch.cuda.current_device())
+    t = _scratch.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
-        _scratch[name] = t
+        _scratch[key] = t
     return t
 
 
