@@ -66,6 +66,43 @@ class OracleTrainer:
         return [l_rpn[1], l_rpn[2], l_det[1], l_det[2], l_det[3]]
 
 
+def oracle_validate(trainer, samples, override_R=None):
+    """The reference's validation loop (train.py:478-561) on an OracleTrainer / OracleTrainerVGG: per sample test_on_batch of
+    the RPN model, proposals from predict_on_batch, calc_iou, get_selected_samples, test_on_batch of the classifier (inference
+    arithmetic: no dropout); a sample without an overlapping RoI is skipped whole (`continue` before the appends).  Weights are
+    not touched.  Returns the list of per-sample records [rpn_cls, rpn_regr, det_cls, det_regr, det_acc, n_pos] of the samples
+    used.  override_R: per sample, proposals to label instead of the oracle's own (the device's: a 1e-7 score difference may
+    legitimately reorder near-tied boxes)."""
+    C, P = trainer.C, trainer.P
+    vgg = getattr(trainer, "vgg", None)
+    out = []
+    for k, s in enumerate(samples):
+        y_cls, y_regr = trainer.targets(s)
+        x = dense.preprocess_caffe_bgr(s["img"])
+        F = vgg.base_forward(P, x) if vgg is not None else dense.base_forward(P, x)
+        p, r, _ = dense.rpn_forward(P, F)
+        l_cls, _ = dense.rpn_loss_cls(y_cls.astype(np.float32), p, trainer.A, trainer.keras2_bce)
+        l_regr, _ = dense.smooth_l1_masked(y_regr.astype(np.float32), r, 4 * trainer.A)
+        R = glue.rpn_to_roi(p, r, C, use_regr=True, overlap_thresh=0.7, max_boxes=300)
+        if override_R is not None:
+            R = override_R[k]
+        gt = np.array([[b["x1"], b["y1"], b["x2"], b["y2"]] for b in s["bboxes"]], dtype=np.float64).reshape(-1, 4)
+        gcls = np.array([C.class_mapping[b["class"]] for b in s["bboxes"]])
+        X2, Y1, Y2, _ = glue.roi_targets(R, gt, gcls, s["width"], s["height"], C)
+        if X2 is None:
+            continue
+        sel, n_pos = glue.select_samples(Y1, C.n_rois)
+        rois = X2[0, sel].astype(np.float32)
+        if vgg is not None:
+            pc, pr, _ = vgg.head_forward(P, F, rois, trainer.nc, None)
+        else:
+            pc, pr, _ = dense.head_forward(P, F, rois, trainer.nc)
+        lc, _ = dense.class_loss_cls(Y1[:, sel].astype(np.float32), pc)
+        lr_, _ = dense.smooth_l1_masked(Y2[:, sel].astype(np.float32), pr, 4 * (trainer.nc - 1))
+        out.append([l_cls, l_regr, lc, lr_, dense.categorical_accuracy(Y1[:, sel].astype(np.float32), pc), n_pos, R])
+    return out
+
+
 class OracleTrainerCont(OracleTrainer):
     """cont_train.py trainability (SURVEY.md 8d cfg 2, secondary): ResNet50 stages 3-4 train in BOTH models, each model's
     Adam keeps its own moments for those shared weights (cont_train.py:169-185), lr 2e-5.  Per iteration: RPN loss ->

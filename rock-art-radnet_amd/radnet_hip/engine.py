@@ -884,6 +884,20 @@ class FasterRCNNEngine:
     def rpn_backward_batched(self, rp):
         self._run(rp["bwd"])
 
+    def rpn_losses_only(self, rp, y_cls, y_regr, loss_out=None):
+        """model_rpn.test_on_batch (train.py:494): the two RPN losses of the forward pass in `rp`, nothing differentiated,
+        no gradient arena touched (the logit gradient the kernel also writes goes to the plan's scratch)."""
+        self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,
+                      self.rpn_losses if loss_out is None else loss_out, self.loss_scratch)
+
+    def head_losses_only(self, hp, loss_out=None):
+        """model_classifier.test_on_batch (train.py:513) on a head plan whose RoIs and targets are packed: forward in inference
+        mode, the two detector losses + accuracy, nothing differentiated."""
+        lo = self.det_losses if loss_out is None else loss_out
+        self.head_forward(hp, training=True, loss_out=lo)          # `training` only selects the fused tail here (no Dropout in this head)
+        if not hp.get("_tail_fused"):
+            self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"], lo)
+
     def rpn_backward(self, rp, y_cls, y_regr, loss_out=None):
         """losses (losses.py:16-66) + gradients of rpn_conv1 / fused heads accumulated into the RPN grad arena."""
         self.ctx.call("radnet_rpn_loss", rp["pred"], RPN_LD, y_cls, y_regr, rp["M"], self.A, self.bce_mode, rp["dz"], RPN_LD,

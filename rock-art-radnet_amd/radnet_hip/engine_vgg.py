@@ -242,6 +242,12 @@ class VGG16Engine(FasterRCNNEngine):
         self.ctx.call("radnet_dense_heads_fwd", hp["d2"], hp["R"], 4096, self.dense_w, self.dense_ld, self.dense_b, self.nc, self.nreg,
                       hp["pcls"], hp["pregr"])
 
+    def head_losses_only(self, hp, loss_out=None):
+        """model_classifier.test_on_batch (train.py:513): Dropout off (Keras test phase), losses + accuracy, no gradients."""
+        self.head_forward(hp, training=False)
+        self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],
+                      self.det_losses if loss_out is None else loss_out)
+
     def head_backward(self, hp, accumulate=False, loss_out=None):
         n = hp["R"] * 4096
         self.ctx.call("radnet_det_loss", hp["pcls"], hp["pregr"], hp["y1"], hp["y2"], hp["R"], self.nc, self.nreg, hp["dz"],

@@ -133,6 +133,66 @@ class TrainStep:
         self._lane_mode = False
         self._finish_head_update()
 
+    VAL_SLOT = 97          # buffer set of the validation pass (plans are keyed by slot: never one of the training step's)
+
+    def validate(self, samples):
+        """The reference's validation loop (train.py:478-561) over an iterable of samples, device-resident and forward only:
+        per sample model_rpn.test_on_batch (RPN losses) -> predict_on_batch -> rpn_to_roi -> calc_iou -> get_selected_samples
+        -> model_classifier.test_on_batch (detector losses, accuracy).  No optimizer step, no gradient arena touched, weights
+        unchanged.  As in the reference a sample whose anchor labelling fails is skipped by the generator (utils.py:461-465) and
+        a sample whose proposals overlap no box is skipped WHOLE -- its RPN losses are not recorded either (`continue` before the
+        appends, train.py:508-509).  NumPy's global stream is drawn from exactly as the reference does (anchor subsampling in the
+        validation generator, then get_selected_samples).  Returns the reference's record: means of the five losses, the mean
+        number of positive RoIs ('mean_overlapping_bboxes', train.py:543) and the total (train.py:544); 'n' samples used."""
+        eng = self.eng
+        C = eng.C
+        if self._lane_mode or self._head_last is not None:
+            self.flush()
+        samples = list(samples)
+        n_max = max(len(samples), 1)
+        rl = torch.zeros(n_max, 2, dtype=torch.float32, device=eng.dev)
+        dl = torch.zeros(n_max, 3, dtype=torch.float32, device=eng.dev)
+        used, n_pos_all, skipped, dropped = [], [], 0, 0
+        for k, s in enumerate(samples):
+            H, W = s["img"].shape[:2]
+            tp = eng.anchor_targets_launch(self._gt(s), s["width"], s["height"], W, H, slot=self.VAL_SLOT)
+            bp = eng.upload_image(s["img"], slot=self.VAL_SLOT)
+            eng.base_forward(bp)
+            rp = eng.rpn_forward(bp)
+            try:
+                ycls, yregr, _ = eng.anchor_targets_finish(tp)
+            except KeyError as e:
+                dropped += 1
+                self._report_drop(s, e)
+                continue
+            eng.rpn_losses_only(rp, ycls, yregr, rl[k])
+            R, Rn = eng.proposals(rp, overlap_thresh=0.7, max_boxes=300)
+            rw, rh = new_img_size(s["width"], s["height"], C.img_size)
+            P, cls, n = eng.roi_targets(R, Rn, self._gt(s), s["width"], s["height"], rw, rh)
+            if self.capture is not None:
+                self.capture.append(dict(pred=rp["pred"].cpu().numpy().copy(), R=R[:max(n, 0)].cpu().numpy().copy()))
+            kept = np.nonzero(cls >= 0)[0]
+            if n <= 0 or len(kept) == 0:
+                skipped += 1
+                continue
+            sel_k, n_pos = E.select_samples(cls[kept], eng.bg, C.n_rois)
+            sel = kept[np.asarray(sel_k, dtype=np.int64)]
+            hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
+            eng.pack_roi_batch(P, sel, hp)
+            eng.head_losses_only(hp, dl[k])
+            used.append(k)
+            n_pos_all.append(n_pos)
+        out = {"n": len(used), "skipped": skipped, "dropped": dropped}
+        if used:
+            r = rl.cpu().numpy()[used].astype(np.float64)
+            d = dl.cpu().numpy()[used].astype(np.float64)
+            out.update(rpn_cls=float(r[:, 0].mean()), rpn_regr=float(r[:, 1].mean()), det_cls=float(d[:, 0].mean()), det_regr=float(d[:, 1].mean()),
+                       det_acc=float(d[:, 2].mean()), mean_overlapping_bboxes=float(sum(n_pos_all)) / len(n_pos_all))
+            out["total"] = out["rpn_cls"] + out["rpn_regr"] + out["det_cls"] + out["det_regr"]
+            out["per_sample"] = [dict(rpn_cls=float(r[i, 0]), rpn_regr=float(r[i, 1]), det_cls=float(d[i, 0]), det_regr=float(d[i, 1]), det_acc=float(d[i, 2]),
+                                      n_pos=int(n_pos_all[i])) for i in range(len(used))]
+        return out
+
     def _gt(self, s):
         """Device copy of a sample's ground truth (cached on the sample: uploaded once)."""
         if "_gt_dev" not in s:

@@ -6,6 +6,8 @@ Tolerances (fp32 MFMA accumulation vs the oracle's fp32 BLAS / fp64 reductions o
   losses       relative 1e-3
 Proposal indices / RoI labels: bit-exact, asserted per stage on identical input tensors.
 """
+import copy
+
 import numpy as np
 import pytest
 
@@ -564,3 +566,61 @@ def test_background_feed_drives_training_with_the_device_resize_on_its_own_strea
     finally:
         bg.close()
     assert not bg._thread.is_alive()
+
+
+def test_validation_pass_vs_oracle():
+    """TrainStep.validate: the reference's validation loop (train.py:478-561) device-resident and forward only -- per sample
+    test_on_batch of the RPN model, proposals, calc_iou, get_selected_samples, test_on_batch of the classifier -- after one
+    training step, against oracle.step.oracle_validate on the same weights: losses per sample, the number of positive RoIs,
+    the consumption of NumPy's global stream; a sample whose boxes no proposal overlaps is skipped whole; weights untouched."""
+    from faster_rcnn.config import Config
+    from oracle import dense, glue, step as ostep
+    from radnet_hip import synth
+    from radnet_hip.engine import FasterRCNNEngine
+    from radnet_hip.trainer import TrainStep
+    C = Config()
+    C.img_size = 300
+    P = dense.init_params(seed=3)
+    eng = FasterRCNNEngine(C)
+    eng.set_weights(P)
+    mk = lambda i, n=6: dict(img=synth.synthetic_panel(30 + i, 300, 500), width=1000, height=600,
+                             bboxes=synth.synthetic_gt(40 + i, n=n, src_w=1000, src_h=600, smin=60, smax=300)["bboxes"])
+    train, val = mk(0), [mk(1), mk(2), mk(3)]
+    val.append(dict(img=synth.synthetic_panel(35, 300, 500), width=1000, height=600,                     # a 6-pixel box in a corner: no proposal reaches IoU 0.1
+                    bboxes=[{"class": "boat", "x1": 990, "x2": 996, "y1": 590, "y2": 596}]))
+    np.random.seed(64)
+    ts = TrainStep(eng)
+    ts.capture = []
+    ts.step([train])
+    R_train = ts.capture[0]["R"]
+    w_before = eng.get_weights()
+    ts.capture = []
+    rec = ts.validate(val)
+    rng_gpu = int(np.random.randint(0, 2 ** 31 - 1))
+    w_after = eng.get_weights()
+    for name in w_before:
+        for k in w_before[name]:
+            assert np.array_equal(w_before[name][k], w_after[name][k]), (name, k)         # forward only
+    assert rec["n"] == 3 and rec["skipped"] == 1 and rec["dropped"] == 0
+    # proposals of the validation pass: bit-exact on the device's own RPN outputs
+    for c in ts.capture:
+        pred = c["pred"]
+        fh, fw = 19, 31
+        Rref = glue.rpn_to_roi(pred[:, :12].reshape(1, fh, fw, 12), pred[:, 12:60].reshape(1, fh, fw, 48), C, True, 300, 0.7)
+        assert np.array_equal(c["R"], Rref)
+    np.random.seed(64)
+    ot = ostep.OracleTrainer(C, copy.deepcopy(P))
+    ot.step(train, override_R=R_train)
+    ref = ostep.oracle_validate(ot, val, override_R=[c["R"] for c in ts.capture])
+    assert rng_gpu == int(np.random.randint(0, 2 ** 31 - 1))
+    assert len(ref) == 3
+    for got, r in zip(rec["per_sample"], ref):
+        assert abs(got["rpn_cls"] - r[0]) < 1e-3 * abs(r[0]) and abs(got["rpn_regr"] - r[1]) < 1e-3 * abs(r[1]) + 1e-6
+        assert abs(got["det_cls"] - r[2]) < 2e-3 * abs(r[2]) and abs(got["det_regr"] - r[3]) < 2e-3 * abs(r[3]) + 1e-5
+        assert abs(got["det_acc"] - r[4]) < 1e-6 and got["n_pos"] == r[5]
+    m = np.array([r[:5] for r in ref], dtype=np.float64).mean(0)
+    assert abs(rec["total"] - m[:4].sum()) < 2e-3 * m[:4].sum()
+    assert rec["mean_overlapping_bboxes"] == sum(r[5] for r in ref) / 3.0
+    # the training step still works after a validation pass (own buffer set, no stale plan)
+    ts.step([train])
+    assert ts.losses()["n_head"] == 1

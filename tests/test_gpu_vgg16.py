@@ -170,6 +170,19 @@ def test_vgg_train_step_vs_oracle(setup):
                 big = np.abs(g) > 1e-3 * np.abs(g).max()
                 assert big.sum() > 0 and np.abs(d_gpu[big] - d_ref[big]).max() < 0.05 * 5e-5, (name, kk, float(np.abs(d_gpu[big] - d_ref[big]).max()))
                 assert np.abs(d_gpu).max() <= 5e-5 * 1.0001
+        # validation pass (train.py:478-561) on the twice-updated weights: Dropout off (Keras test phase), forward only
+        ts.capture = []
+        np.random.seed(7)
+        rec = ts.validate([samples[1]])
+        rng_v = int(np.random.randint(0, 2 ** 31 - 1))
+        np.random.seed(7)
+        vref = ostep.oracle_validate(ot, [samples[1]], override_R=[ts.capture[0]["R"]])
+        assert rng_v == int(np.random.randint(0, 2 ** 31 - 1))
+        assert rec["n"] == 1 and len(vref) == 1
+        g_, r_ = rec["per_sample"][0], vref[0]
+        assert abs(g_["rpn_cls"] - r_[0]) < 1e-3 * abs(r_[0]) and abs(g_["rpn_regr"] - r_[1]) < 1e-3 * abs(r_[1]) + 1e-6
+        assert abs(g_["det_cls"] - r_[2]) < 3e-3 * abs(r_[2]) and abs(g_["det_regr"] - r_[3]) < 3e-3 * abs(r_[3]) + 1e-5
+        assert abs(g_["det_acc"] - r_[4]) < 1e-6 and g_["n_pos"] == r_[5]
     finally:
         C.img_size = old_size
         eng.forced_masks = None
