@@ -99,20 +99,21 @@ def _time_us(fn, n=30, warm=5):
 
 def committed_pmc_traffic():
     """HBM bytes per launch of the dominant GEMM kernel from the committed PMC passes of this same command
-    (profiles/r02_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
+    (profiles/r03_pmc_summary.txt, else the previous round's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
     tools/collect_profiles.sh, FETCH_SIZE doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  A profiler
     cannot run inside this process: the figure is the last committed measurement, or None when the file is not there."""
     import re
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.txt")
-    try:
-        for line in open(path):
-            m = re.search(r"^\s*(conv_igemm_kernel<64, 64, 0, false, 4>)\s+per launch: FETCH_SIZE\s+([0-9.]+) MB \(x2 =\s+([0-9.]+) MB\)\s+WRITE_SIZE\s+([0-9.]+) MB", line)
-            if m:
-                return {"kernel": m.group(1), "bytes": (float(m.group(3)) + float(m.group(4))) * 1e6,
-                        "fetch_bytes_corrected": float(m.group(3)) * 1e6, "write_bytes": float(m.group(4)) * 1e6,
-                        "source": "profiles/r02_pmc_summary.txt (separate --pmc passes of this command; not measured in this run)"}
-    except OSError:
-        pass
+    for name in ("r03_pmc_summary.txt", "r02_pmc_summary.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            for line in open(path):
+                m = re.search(r"^\s*(conv_igemm_kernel<64, 64, 0, false, 4>)\s+per launch: FETCH_SIZE\s+([0-9.]+) MB \(x2 =\s+([0-9.]+) MB\)\s+WRITE_SIZE\s+([0-9.]+) MB", line)
+                if m:
+                    return {"kernel": m.group(1), "bytes": (float(m.group(3)) + float(m.group(4))) * 1e6,
+                            "fetch_bytes_corrected": float(m.group(3)) * 1e6, "write_bytes": float(m.group(4)) * 1e6,
+                            "source": "profiles/%s (separate --pmc passes of this command; not measured in this run)" % name}
+        except OSError:
+            pass
     return None
 
 
@@ -450,6 +451,9 @@ def main():
                                     "pipelined over HIP streams: %d prefetch lanes (frozen base forward, %d batches ahead%s), RPN phase, head phase"
                                     % (getattr(eng, "n_side_lanes", 1), LOOK,
                                        ", two consecutive batches' base forwards as one nb=2 program" if getattr(ts, "stack_base", False) and args.per_gpu_batch == 1 else "")),
+                       "reductions": ("ordered (radnet_set_deterministic: no floating-point atomics in the step; bit-identical across runs and schedules)"
+                                      if os.environ.get("RADNET_DETERMINISTIC", "1") != "0" else "fp32 atomics (RADNET_DETERMINISTIC=0)"),
+                       "base_forward": ("chain kernel, %d workgroups (RADNET_CHAIN=1)" % (getattr(eng, "chain_wgs", 0) or 512)) if getattr(eng, "use_chain", False) else "launch list (hipGraph)",
                        "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
                        "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},
             "losses": losses,
