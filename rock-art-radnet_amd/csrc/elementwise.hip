@@ -134,11 +134,20 @@ __global__ void __launch_bounds__(64) roi_resize_bwd_ordered_kernel(const float*
       const bool top = g.y0 + ylo == y, bot = g.y0 + yhi == y;
       if (!top && !bot) continue;
       touched = true;
-      for (int ox = 0; ox < ps; ++ox) {
+      // the ps values of this output row first, all loads in flight together (one at a time this loop ran at one memory
+      // round trip per output pixel: 218 us for 20 RoIs at 38x63), then the adds in column order
+      constexpr int kMaxPs = 14;
+      float vrow[kMaxPs];
+      const float* src = dy + ((long long)(r * ps + oy) * ps) * C + c;
+#pragma unroll
+      for (int ox = 0; ox < kMaxPs; ++ox) vrow[ox] = (live && ox < ps) ? src[(long long)ox * C] : 0.f;
+#pragma unroll
+      for (int ox = 0; ox < kMaxPs; ++ox) {
+        if (ox >= ps) break;
         const float sx = (float)ox * ws;
         const int xlo = (int)floorf(sx), xhi = min(xlo + 1, g.cw - 1);
         const float lx = sx - (float)xlo;
-        const float v = live ? dy[((long long)(r * ps + oy) * ps + ox) * C + c] : 0.f;
+        const float v = vrow[ox];
         float* lo = row + (g.x0 + xlo) * 64 + threadIdx.x;
         float* hi = row + (g.x0 + xhi) * 64 + threadIdx.x;
         if (top) {
@@ -575,7 +584,7 @@ extern "C" int radnet_roi_resize_bwd(radnet_ctx* ctx, const float* dy, int32_t h
                                      int32_t ps, float* dfmap) {
   if (!ctx || !dy || !rois || !dfmap) return RADNET_ERR_ARG;
   const size_t smem = (size_t)w * 64 * sizeof(float);
-  if (ctx->deterministic && smem <= 64 * 1024)
+  if (ctx->deterministic && smem <= 64 * 1024 && ps <= 14)
     hipLaunchKernelGGL(roi_resize_bwd_ordered_kernel, dim3(h, radnet_cdiv(c, 64)), dim3(64), smem, ctx->stream, dy, h, w, c, rois, r, ps, dfmap);
   else
     hipLaunchKernelGGL(roi_resize_bwd_kernel, dim3(r * ps * ps), dim3(256), 0, ctx->stream, dy, h, w, c, rois, ps, dfmap);
