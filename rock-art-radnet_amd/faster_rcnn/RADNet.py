@@ -223,6 +223,37 @@ class RADNet():
             out.append(self._per_class_nms(bboxes, probs, ratio))
         return out
 
+    # ---- tiles over the ranks of a data-parallel job (inference) ------------------------------------------
+    def set_distributed(self, group=None, enabled=True):
+        """Shard the tiles of every image round-robin over the ranks of torch.distributed's `group` (default: the world):
+        each rank runs the network passes of its tiles, the per-tile detections (a few hundred boxes: KB) are exchanged with
+        all_gather_object, and every rank then runs the merge tail (final_nms per image, NMS across images) on the tiles IN
+        THEIR ORIGINAL ORDER -- so every rank returns exactly what a single process returns.  The reference is single-process
+        (predict.py:56-122); this is its tile loop (RADNet.py:540-600) spread over GPUs, nothing else changes."""
+        self._dist_group = group
+        self._dist_on = bool(enabled)
+
+    def _detect_sharded(self, work):
+        import torch.distributed as dist
+        if not getattr(self, "_dist_on", False) or not (dist.is_available() and dist.is_initialized()):
+            return self._detect_all(work)
+        group = getattr(self, "_dist_group", None)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world == 1:
+            return self._detect_all(work)
+        mine = list(range(rank, len(work), world))
+        local = self._detect_all([work[j] for j in mine]) if mine else []
+        # plain Python containers on the wire (class name -> ([[x1, y1, x2, y2], ...], [prob, ...]))
+        payload = [(j, {k: ([[int(v) for v in b] for b in real], [float(p) for p in pr]) for k, (real, pr) in det.items()}) for j, det in zip(mine, local)]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload, group=group)
+        out = [None] * len(work)
+        for part in gathered:
+            for j, det in part:
+                out[j] = {k: ([tuple(b) for b in real], [np.float32(p) for p in pr]) for k, (real, pr) in det.items()}
+        assert all(o is not None for o in out)
+        return out
+
     def predict(self, images):
         """RADNet.py:502-718: tile -> RPN -> NMS -> RoI crop-resize -> classifier -> per-class NMS, box-averaging
         merge per image, then NMS 0.4 across images."""
@@ -244,7 +275,7 @@ class RADNet():
                 spans = []
             work = [np.copy(img[ty0:ty1, tx0:tx1, :]) for (tx0, ty0, tx1, ty1) in spans] + ([img] if C.include_full_img else [])
             offs = [(tx0, ty0) for (tx0, ty0, tx1, ty1) in spans] + ([(0, 0)] if C.include_full_img else [])
-            for det, (ox, oy) in zip(self._detect_all(work), offs):
+            for det, (ox, oy) in zip(self._detect_sharded(work), offs):
                 collect(det, ox, oy)
             for key in boxes_img:
                 nb, npr = self.final_nms(np.array(boxes_img[key]), np.array(probs_img[key]), obj_avg_threshold=0.2,
