@@ -159,7 +159,9 @@ class FasterRCNNEngine:
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
         # frozen base forward (stages 2-4) as one persistent launch of `chain_wgs` workgroups (0: two per CU); DESIGN.md 4
         self.use_chain = os.environ.get("RADNET_CHAIN", "0") == "1"
-        self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "0"))
+        # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
+        # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
+        self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
