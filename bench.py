@@ -462,6 +462,9 @@ def main():
                                        ", two consecutive batches' base forwards as one nb=2 program" if getattr(ts, "stack_base", False) and args.per_gpu_batch == 1 else "")),
                        "reductions": ("ordered (radnet_set_deterministic: no floating-point atomics in the step; bit-identical across runs and schedules)"
                                       if os.environ.get("RADNET_DETERMINISTIC", "1") != "0" else "fp32 atomics (RADNET_DETERMINISTIC=0)"),
+                       "launch_shapes": (("table %s" % os.path.basename(args.tune_cache)) if have_cache else
+                                         ("tuned in situ, shipped (%s) + measured on first use" % ", ".join(eng.shipped_tuning)) if getattr(eng, "shipped_tuning", None)
+                                         else "measured per shape on first use"),
                        "base_forward": ("chain kernel, %d workgroups (RADNET_CHAIN=1)" % (getattr(eng, "chain_wgs", 0) or 512)) if getattr(eng, "use_chain", False) else "launch list (hipGraph)",
                        "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
                        "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},

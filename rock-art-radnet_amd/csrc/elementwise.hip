@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) dense_heads_bwd_kernel(const float* __res
 
 // ---- column sums (bias gradients) ----------------------------------------------------------------------
 // `partials` != null (radnet_ctx::deterministic): the row blocks of a column block hand their partial sums to the last one
-// to arrive, which adds them in row-block order (sc1 stores / relaxed agent-scope ticket / sc1 loads, as the split-K
+// to arrive, which adds them in a fixed shape (sc1 stores / relaxed agent-scope ticket / sc1 loads, as the split-K
 // reduction of conv_mfma.hip) -- the same bits on every run.  partials == null: one fp32 atomic per block and column.
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int m, int n, int ld, const float* __restrict__ gscale,
                                                      float* __restrict__ out, int rows_per_block, float* __restrict__ partials,
@@ -313,10 +313,16 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
     if (s_last) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!s_last || ty != 0 || col >= n) return;
+  if (!s_last) return;                     // uniform for the workgroup
+  // fixed shape: wave ty adds row blocks ty, ty + 4, ... in order, then the four waves in order
   float t = 0.f;
-  for (unsigned b = 0; b < gridDim.y; ++b)
-    t += __hip_atomic_load(partials + (size_t)b * kAuxColsumCols + blockIdx.x * 64 + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (col < n)
+    for (unsigned b = ty; b < gridDim.y; b += 4)
+      t += __hip_atomic_load(partials + (size_t)b * kAuxColsumCols + blockIdx.x * 64 + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  red[ty][tx] = t;                         // every thread read red[] before the barriers above
+  __syncthreads();
+  if (ty != 0 || col >= n) return;
+  t = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
   if (gscale) t *= gscale[col];
   out[col] += t;                   // this workgroup is the only writer of its 64 columns in the launch
 }
@@ -393,8 +399,9 @@ __global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restr
     if (threadIdx.x < 4) atomicAdd(scratch + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
     return;
   }
-  // ordered form: the blocks' sums are added in block order by the last block to arrive (scratch[4] holds the arrival
-  // counter, zeroed with the rest of scratch by the launcher's memset)
+  // ordered form: the last block to arrive adds the blocks' sums in a fixed shape (thread t takes blocks t, t + 256, ...; then the
+  // wave shuffle tree; then the four waves in order) -- the same bits on every run, and one memory round trip instead of one per
+  // block.  scratch[4] holds the arrival counter, zeroed with the rest of scratch by the launcher's memset.
   __shared__ int s_last;
   if (threadIdx.x < 4)
     __hip_atomic_store(partials + 4 * blockIdx.x + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x],
@@ -406,11 +413,19 @@ __global__ void __launch_bounds__(256) rpn_loss_sums_kernel(const float* __restr
     s_last = ticket == gridDim.x - 1;
   }
   __syncthreads();
-  if (s_last && threadIdx.x < 4) {
-    double t = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b) t += __hip_atomic_load(partials + 4 * b + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    scratch[threadIdx.x] = t;
+  if (!s_last) return;                     // uniform for the workgroup
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+    t0 += __hip_atomic_load(partials + 4 * b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t1 += __hip_atomic_load(partials + 4 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t2 += __hip_atomic_load(partials + 4 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t3 += __hip_atomic_load(partials + 4 * b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  t0 = wave_sum_d(t0); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2); t3 = wave_sum_d(t3);
+  // red[] was last read before the two barriers above
+  if (lane == 0) { red[wave][0] = t0; red[wave][1] = t1; red[wave][2] = t2; red[wave][3] = t3; }
+  __syncthreads();
+  if (threadIdx.x < 4) scratch[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256) rpn_loss_grad_kernel(const float* __restrict__ pred, int ld_pred, const float* __restrict__ ycls,

@@ -204,6 +204,16 @@ class FasterRCNNEngine:
                 c.check(self.lib.radnet_force_config(c.h, fa, fb, fs), "force_config")
         for c in [self.ctx2, self.ctx3] + [e[1] for e in self._extra_lanes]:           # one table of measured launch choices for all lanes
             self.ctx.check(self.lib.radnet_share_tuning(c.h, self.ctx.h), "share_tuning")
+        # Launch shapes tuned IN SITU for known workloads (tools/insitu_tune.py: against the throughput of the pipelined step, where a
+        # launch shares the chip with the other lanes', instead of each launch alone): radnet_hip/tuned/*.txt, loaded before anything
+        # is measured.  Keys are exact problem shapes; every other shape is measured on first use as before.  RADNET_SHIPPED_TUNING=0: off.
+        self.shipped_tuning = []
+        tuned_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+        if self.autotune_mode and os.environ.get("RADNET_SHIPPED_TUNING", "1") != "0" and os.path.isdir(tuned_dir):
+            for name in sorted(os.listdir(tuned_dir)):
+                if name.endswith(".txt"):
+                    self.load_tuning(os.path.join(tuned_dir, name))
+                    self.shipped_tuning.append(name)
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]
                                    for s in C_cfg.anchor_box_scales for r in C_cfg.anchor_box_ratios], dtype=np.float64)
         self.anchor_sizes = np.array(C_cfg.anchor_box_scales, dtype=np.float64)

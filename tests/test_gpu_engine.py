@@ -434,7 +434,7 @@ def test_run_training_from_tile_feed():
     assert diff is None, diff
 
 
-def test_default_config_augmentations_train_on_changing_tile_sizes():
+def test_default_config_augmentations_train_on_changing_tile_sizes(monkeypatch):
     """The reference's DEFAULT Config has every augmentation on (config.py:19-26); rotation and shear change the tile size
     from sample to sample.  TileFeed -> TrainStep with the default switches: every step finishes with finite losses, sizes do
     change, and with autotune mode 2 (adopt the nearest measured M) later new sizes plan much faster than the first ones."""
@@ -459,6 +459,7 @@ def test_default_config_augmentations_train_on_changing_tile_sizes():
         data.append({"filepath": "img%d" % i, "width": w, "height": h, "bboxes": boxes})
         imgs["img%d" % i] = rs.randint(1, 256, (h, w, 3)).astype(np.uint8)
     class_count = {c: sum(1 for d in data for b in d["bboxes"] if b["class"] == c) for c in classes}
+    monkeypatch.setenv("RADNET_SHIPPED_TUNING", "0")     # the first step must measure its shapes itself: that is what `took[0]` stands for
     eng = FasterRCNNEngine(C, autotune=2)
     eng.set_weights(dense.init_params(seed=3))
     np.random.seed(11)
