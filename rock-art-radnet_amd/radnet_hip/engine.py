@@ -125,6 +125,7 @@ class FasterRCNNEngine:
 
     NETWORK = "resnet50"
     N_FEATURES = 1024
+    TUNED_PREFIX = "train_"      # which shipped launch-shape tables (radnet_hip/tuned/) this engine's workload is: the pipelined train.py step
     supports_batched = True      # per-GPU mini-batch as one layer program (upload_images / _plan_rpn(nb) / _plan_head(groups))
     feat_len = staticmethod(feat_len)
 
@@ -206,12 +207,13 @@ class FasterRCNNEngine:
             self.ctx.check(self.lib.radnet_share_tuning(c.h, self.ctx.h), "share_tuning")
         # Launch shapes tuned IN SITU for known workloads (tools/insitu_tune.py: against the throughput of the pipelined step, where a
         # launch shares the chip with the other lanes', instead of each launch alone): radnet_hip/tuned/*.txt, loaded before anything
-        # is measured.  Keys are exact problem shapes; every other shape is measured on first use as before.  RADNET_SHIPPED_TUNING=0: off.
+        # is measured.  Keys are exact problem shapes; every other shape is measured on first use as before.  A table belongs to the
+        # workload it was tuned in (file name prefix = TUNED_PREFIX of the engine class).  RADNET_SHIPPED_TUNING=0: off.
         self.shipped_tuning = []
         tuned_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
         if self.autotune_mode and os.environ.get("RADNET_SHIPPED_TUNING", "1") != "0" and os.path.isdir(tuned_dir):
             for name in sorted(os.listdir(tuned_dir)):
-                if name.endswith(".txt"):
+                if name.endswith(".txt") and name.startswith(self.TUNED_PREFIX):
                     self.load_tuning(os.path.join(tuned_dir, name))
                     self.shipped_tuning.append(name)
         self.anchor_wh = np.array([[(s * r[0]) / C_cfg.rpn_stride, (s * r[1]) / C_cfg.rpn_stride]

@@ -8,7 +8,7 @@ form), re-records the layer programs, times a few hundred pipelined steps and ke
 more than the noise, twice.  The result is an ordinary tuning table (radnet_tune_save format) for `bench.py --tune-cache` /
 `engine.load_tuning`.
 
-usage: python tools/insitu_tune.py <out table> [--passes 1] [--steps 200] [--budget-s 900] [--start <table>] [--per-gpu-batch 1]"""
+usage: python tools/insitu_tune.py <out table> [--passes 1] [--steps 200] [--budget-s 900] [--start <table>] [--per-gpu-batch 1] [--trainable train|cont]"""
 import argparse
 import os
 import sys
@@ -110,14 +110,31 @@ def main():
     ap.add_argument("--budget-s", type=float, default=900.0)
     ap.add_argument("--start", default=None, help="table to start from instead of this process's autotuning")
     ap.add_argument("--gain", type=float, default=0.0025, help="relative step-time gain a change must show, twice")
+    ap.add_argument("--trainable", choices=("train", "cont"), default="train")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
     args = ap.parse_args()
     t_begin = time.perf_counter()
-    eng = make_engine(Config())
-    eng.set_weights(synth.synthetic_weights(seed=3))
+    if args.trainable == "cont":           # cont_train.py mode: stages 3-4 train in both models, one lane (bench.py --trainable cont)
+        from radnet_hip.engine_cont import ContEngine
+        from radnet_hip.trainer_cont import ContTrainStep
+        eng = ContEngine(Config())
+        eng.set_weights(synth.synthetic_weights(seed=3))
+        _ts = ContTrainStep(eng)
+
+        class _Adapter:
+            def step(self, batch, upcoming=None):
+                return _ts.step(batch, upcoming=upcoming)
+
+            def flush(self):
+                pass
+
+        ts = _Adapter()
+    else:
+        eng = make_engine(Config())
+        eng.set_weights(synth.synthetic_weights(seed=3))
+        ts = TrainStep(eng)
     if args.start:
         eng.load_tuning(args.start)
-    ts = TrainStep(eng)
     batch = bench.make_batch(0, args.per_gpu_batch, 600, 1000)
     look = getattr(ts, "LOOKAHEAD", 3)
     n_prime = 2 * getattr(ts, "NBUF", 6) + 6
