@@ -16,6 +16,7 @@ import time
 
 import torch
 
+os.environ["RADNET_SHIPPED_TUNING"] = "0"      # start from what the engine measures itself (or --start), never from a shipped table
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
 
@@ -55,6 +56,9 @@ def write_table(path, tab, header):
             f.write("%s %d %d %d %.6f %d\n" % (" ".join(str(v) for v in key), a, b, s, ms, w))
 
 
+WIDE = False      # --wide: every K-slice count (both unit orders) instead of the two or three next to the current one
+
+
 def neighbours(key, cur):
     """Launch shapes next to `cur` inside the autotuner's own candidate space (conv_mfma.hip: run_igemm / run_wgrad)."""
     kind, m, n, k, c, npos, stride = key
@@ -68,7 +72,7 @@ def neighbours(key, cur):
         if not batched:
             i = WGRAD_SLICES.index(s) if s in WGRAD_SLICES else None
             if i is not None:
-                for j in (i - 1, i + 1, i + 2):
+                for j in (range(len(WGRAD_SLICES)) if WIDE else (i - 1, i + 1, i + 2)):
                     if 0 <= j < len(WGRAD_SLICES) and ok(WGRAD_SLICES[j]):
                         out.append((a, b, WGRAD_SLICES[j], w))
         for ta in (64, 128):
@@ -81,11 +85,13 @@ def neighbours(key, cur):
         mag = abs(s)
         i = FWD_SLICES.index(mag) if mag in FWD_SLICES else None
         if i is not None:
-            for j in (i - 1, i + 1, i + 2):
+            for j in (range(len(FWD_SLICES)) if WIDE else (i - 1, i + 1, i + 2)):
                 if 0 <= j < len(FWD_SLICES):
                     v = FWD_SLICES[j]
                     if v == 1 or nk // v >= 2:
                         out.append((a, b, v if s > 0 else -v, w))
+                        if WIDE and cdiv(m, a) * cdiv(n, b) * v >= 16:
+                            out.append((a, b, -v if s > 0 else v, w))
         tiles = cdiv(m, a) * cdiv(n, b)
         if tiles * abs(s) >= 16:
             out.append((a, b, -s, w))                      # the other workgroup order (plain / XCD-contiguous)
@@ -110,9 +116,12 @@ def main():
     ap.add_argument("--budget-s", type=float, default=900.0)
     ap.add_argument("--start", default=None, help="table to start from instead of this process's autotuning")
     ap.add_argument("--gain", type=float, default=0.0025, help="relative step-time gain a change must show, twice")
+    ap.add_argument("--wide", action="store_true", help="try every K-slice count of a shape, not only the neighbouring ones")
     ap.add_argument("--trainable", choices=("train", "cont"), default="train")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
     args = ap.parse_args()
+    global WIDE
+    WIDE = args.wide
     t_begin = time.perf_counter()
     if args.trainable == "cont":           # cont_train.py mode: stages 3-4 train in both models, one lane (bench.py --trainable cont)
         from radnet_hip.engine_cont import ContEngine
@@ -133,8 +142,6 @@ def main():
         eng = make_engine(Config())
         eng.set_weights(synth.synthetic_weights(seed=3))
         ts = TrainStep(eng)
-    if args.start:
-        eng.load_tuning(args.start)
     batch = bench.make_batch(0, args.per_gpu_batch, 600, 1000)
     look = getattr(ts, "LOOKAHEAD", 3)
     n_prime = 2 * getattr(ts, "NBUF", 6) + 6
@@ -162,10 +169,17 @@ def main():
         run(n_prime)
         torch.cuda.synchronize()
 
+    # the shapes THIS workload launches: what the engine measures on its own when it starts from an empty table (shipped tables
+    # may hold other workloads' shapes; a change to a shape that is never launched can only "win" by noise)
     run(n_prime)
     torch.cuda.synchronize()
     eng.save_tuning(tmp)
     tab, header = read_table(tmp)
+    if args.start:
+        used = set(tab)
+        start_tab, _ = read_table(args.start)
+        tab.update({k: v for k, v in start_tab.items() if k in used})
+        apply(tab, header)
     best = min(measure(), measure())
     print("start: %d entries, step %.1f us (%.1f images/s)" % (len(tab), best, 1e6 / best), flush=True)
     start_us = best
@@ -193,6 +207,13 @@ def main():
                     ok = t1 < best * (1.0 - args.gain)
                     t2 = measure() if ok else t1
                     ok = ok and t2 < best * (1.0 - args.gain)
+                    if ok:                     # A / B / A: the table without the change, measured again now, must still lose
+                        apply(tab, header)
+                        ref = min(measure(), measure())
+                        ok = max(t1, t2) < ref * (1.0 - args.gain)
+                        print("    reference now %.1f us" % ref, flush=True)
+                        if not ok:
+                            best = ref
                 except RuntimeError as e:      # the step's state is unknown after a failed launch: stop with what is kept so far
                     print("  %s -> %s: %s -- stopping" % (key, cand, str(e).splitlines()[0][:160]), flush=True)
                     write_table(args.out, tab, header)
