@@ -1341,14 +1341,20 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int chunks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};      // K slices per tile
     std::vector<std::pair<float, TileChoice>> seen;
+    // A data gradient measured on behalf of radnet_conv_bwd is tuned WITHIN the shapes its one-launch form takes (64x64 tiles,
+    // 4 waves): alone on the chip the 8-wave form often wins by a few per cent, but next to other lanes' launches the paired
+    // launch beat "fastest dgrad + wgrad, one after the other" for every classifier layer measured in situ (tools/insitu_tune.py:
+    // +2.7 % and +1.3 % on the whole step for the two layers the isolated choice had unpaired)
+    const bool for_pair = pause.saved != nullptr && bmode == 1 && !smallc && g.batch <= 1;
     for (int c = 0; c < 4; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
+      if (for_pair && (cand[c][0] != 64 || cand[c][1] != 64)) continue;
       const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
       for (int s : chunks) {
         if (s > 1 && (ctx->ws == nullptr || nk / s < 2)) continue;               // slices shorter than 2 k-tiles
         for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
           if (sign < 0 && tiles * s < 16) continue;
-          for (int waves = 4; waves <= 8; waves += 4) {                         // 8 = K tile halved between two wave grids
+          for (int waves = 4; waves <= (for_pair ? 4 : 8); waves += 4) {        // 8 = K tile halved between two wave grids
             TileChoice t{cand[c][0], cand[c][1], sign * s, waves};
             float ms = 0.f;
             int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
@@ -1805,10 +1811,13 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     PairPause pause(ctx);                       // trial launches are real launches
     struct WCand { float ms; int bmk, bn, s; };
     std::vector<WCand> seen;
+    const bool for_pair = pause.saved != nullptr && batch <= 1 && d->dx != nullptr;      // see run_igemm
     for (int cb = 128; cb >= 64; cb -= 64) {
       if (d->c % cb) continue;
+      if (for_pair && cb != 64) continue;
       for (int cn = 128; cn >= 64; cn -= 64) {
         if (cn > 64 && g.N <= 64) continue;
+        if (for_pair && cn != 64) continue;
         for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
           if (s > 1 && (nmt / s < 2 || radnet_cdiv(nmt, radnet_cdiv(nmt, s)) != s)) continue;
           float ms = 0.f;

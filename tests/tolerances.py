@@ -9,7 +9,10 @@ FMA epilogues on the device against the oracle's float64 / BLAS sums), as ONE ch
   3. RMS            ||a - b||_2 <= RMS_FRACTION * tol * ||b||_2          (errors must look like rounding noise -- centred, a
                     tenth of the worst-case bound -- not like a systematic offset that happens to stay under (1))
 
-`tol` is the figure each test states (activations 1e-3, gradients 2e-3, VGG fc gradients 3e-3).  One-dimensional arrays (bias
+`tol` is the figure each test states (activations 1e-3, gradients 2e-3, VGG fc gradients 3e-3).  `floor` (default FLOOR) can be raised by a call site whose error is not rounding noise of ONE sum: gradients
+that pass through ReLU masks differ from the oracle's by whole terms wherever an activation lands within rounding of zero on one
+side only (measured: 2e-5 ... 2e-4 of the largest gradient for res5a's kernels at 1000x600, against 5e-7 for the layers behind
+no such mask) -- in a channel whose own gradients are that small the per-channel bound must start from that level.  One-dimensional arrays (bias
 gradients) have no channel axis: criteria 1 and 3.  RADNET_TOL_REPORT=1 prints the three measured ratios per call instead of
 asserting (used once per round on the GPU box to see how far below the bounds the kernels sit; profiles/r03_tolerance_report.txt)."""
 import os
@@ -21,7 +24,7 @@ RMS_FRACTION = 0.1
 _REPORT = os.environ.get("RADNET_TOL_REPORT", "0") == "1"
 
 
-def measure(a, b):
+def measure(a, b, floor=FLOOR):
     """-> (max-norm ratio, worst per-channel excess ratio [<= 1 passes when scaled by tol], rms ratio)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -34,16 +37,16 @@ def measure(a, b):
     if a.ndim >= 2 and a.shape[-1] > 1:
         dc = d.reshape(-1, a.shape[-1]).max(0)
         bc = np.abs(b).reshape(-1, b.shape[-1]).max(0)
-        chan = dc / (bc + FLOOR * gmax)           # compared with tol
+        chan = dc / (bc + floor * gmax)           # compared with tol
     return max_ratio, chan, rms_ratio
 
 
-def check(a, b, tol, what=""):
+def check(a, b, tol, what="", floor=FLOOR):
     if not what:                                   # the call site names the comparison
         import sys
         f = sys._getframe(1)
         what = "%s:%d" % (os.path.basename(f.f_code.co_filename), f.f_lineno)
-    max_ratio, chan, rms_ratio = measure(a, b)
+    max_ratio, chan, rms_ratio = measure(a, b, floor)
     worst = float(chan.max()) if chan is not None else float("nan")
     if _REPORT:
         print("[tol] %-44s tol %.0e  max-norm %.2e  worst-channel %.2e  rms %.2e (bound %.0e)" % (what, tol, max_ratio, worst, rms_ratio, RMS_FRACTION * tol))
