@@ -99,11 +99,11 @@ def _time_us(fn, n=30, warm=5):
 
 def committed_pmc_traffic():
     """HBM bytes per launch of the dominant GEMM kernel from the committed PMC passes of this same command
-    (profiles/r03_pmc_summary.txt, else the previous round's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
+    (profiles/r03_pmc_summary_insitu_tables.txt, else the earlier ones: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
     tools/collect_profiles.sh, FETCH_SIZE doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  A profiler
     cannot run inside this process: the figure is the last committed measurement, or None when the file is not there."""
     import re
-    for name in ("r03_pmc_summary.txt", "r02_pmc_summary.txt"):
+    for name in ("r03_pmc_summary_insitu_tables.txt", "r03_pmc_summary.txt", "r02_pmc_summary.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             for line in open(path):
