@@ -1,0 +1,74 @@
+"""Shipped launch-shape tables (radnet_hip/tuned/) and the in-situ tuner's candidate generator: host logic, no GPU."""
+import glob
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TUNED = os.path.join(ROOT, "rock-art-radnet_amd", "radnet_hip", "tuned")
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("insitu_tune", os.path.join(ROOT, "tools", "insitu_tune.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _valid(key, a, b, s, w):
+    """What csrc/conv_mfma.hip (run_igemm / run_wgrad) and radnet_tune_load accept for a measured shape."""
+    kind, m, n, k, c, npos, stride = key
+    assert a in (64, 128) and b in (64, 128) and w in (4, 8) and s != 0 and abs(s) <= 64, (key, a, b, s, w)
+    wgrad = (kind & 7) in (2, 3)
+    if kind >= 8:
+        assert s == 1, (key, s)                                     # a batch is its own source of workgroups
+    if wgrad:
+        assert c % a == 0 and s >= 1 and w == 4, (key, a, s, w)
+        nmt = (m + 31) // 32
+        if s > 1:
+            assert nmt // s >= 2 and -(-nmt // -(-nmt // s)) == s, (key, s)     # no empty pixel split
+    else:
+        if b > 64:
+            assert n > 64, (key, b)
+        if abs(s) > 1:
+            assert ((k + 31) // 32) // abs(s) >= 2, (key, s)          # a K slice holds at least two k tiles
+
+
+def test_shipped_tables_parse_and_hold_valid_shapes():
+    T = _tool()
+    files = sorted(glob.glob(os.path.join(TUNED, "*.txt")))
+    assert files, "no shipped tables"
+    seen = {}
+    for path in files:
+        name = os.path.basename(path)
+        assert name.startswith(("train_", "cont_")), name           # an engine loads the tables of its workload (engine.TUNED_PREFIX)
+        tab, header = T.read_table(path)
+        assert header is not None and header.startswith("# radnet tuned GEMM launch shapes v2") or open(path).readline().startswith("# radnet tuned GEMM launch shapes v2")
+        assert len(tab) >= 10, (name, len(tab))
+        for key, (a, b, s, ms, w) in tab.items():
+            _valid(key, a, b, s, w)
+            assert key not in seen, "%s repeats %r of %s" % (name, key, seen.get(key))    # load order must not matter
+            seen[key] = name
+
+
+def test_insitu_neighbours_stay_inside_the_tuners_candidate_space():
+    T = _tool()
+    for path in sorted(glob.glob(os.path.join(TUNED, "*.txt"))):
+        tab, _ = T.read_table(path)
+        for wide in (False, True):
+            T.WIDE = wide
+            for key, cur in tab.items():
+                cands = T.neighbours(key, cur)
+                assert len(cands) == len(set(cands)) and (cur[0], cur[1], cur[2], cur[4]) not in cands
+                for a, b, s, w in cands:
+                    _valid(key, a, b, s, w)
+    T.WIDE = False
+
+
+def test_table_round_trip(tmp_path):
+    T = _tool()
+    src = sorted(glob.glob(os.path.join(TUNED, "*.txt")))[0]
+    tab, header = T.read_table(src)
+    out = tmp_path / "t.txt"
+    T.write_table(str(out), tab, header)
+    tab2, _ = T.read_table(str(out))
+    assert tab2 == tab

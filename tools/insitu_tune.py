@@ -14,16 +14,7 @@ import os
 import sys
 import time
 
-import torch
-
-os.environ["RADNET_SHIPPED_TUNING"] = "0"      # start from what the engine measures itself (or --start), never from a shipped table
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
-
-import bench  # noqa: E402
-from faster_rcnn.config import Config  # noqa: E402
-from radnet_hip import make_engine, synth  # noqa: E402
-from radnet_hip.trainer import TrainStep  # noqa: E402
 
 BK = 32
 FWD_SLICES = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16]
@@ -79,7 +70,7 @@ def neighbours(key, cur):
             for tb in (64, 128):
                 if (ta, tb) != (a, b) and c % ta == 0 and not (tb > 64 and n <= 64):
                     out.append((ta, tb, s, w))
-        return out
+        return [o for i, o in enumerate(out) if o != (a, b, s, w) and o not in out[:i]]
     nk = cdiv(k, BK)
     if not batched:
         mag = abs(s)
@@ -122,6 +113,13 @@ def main():
     args = ap.parse_args()
     global WIDE
     WIDE = args.wide
+    os.environ["RADNET_SHIPPED_TUNING"] = "0"      # start from what the engine measures itself (or --start), never from a shipped table
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
+    import torch
+    import bench
+    from faster_rcnn.config import Config
+    from radnet_hip import make_engine, synth
+    from radnet_hip.trainer import TrainStep
     t_begin = time.perf_counter()
     if args.trainable == "cont":           # cont_train.py mode: stages 3-4 train in both models, one lane (bench.py --trainable cont)
         from radnet_hip.engine_cont import ContEngine
