@@ -77,6 +77,7 @@ struct GemmArgs {
   long long x_bstride, w_bstride, y_bstride;   // floats between consecutive problems of a batch
   unsigned* counters;          // K-split launches: arrival counter per output tile (zero outside a launch)
   unsigned long long* stamps;  // diagnostic build only (RADNET_DIAG_STAMPS): 8 words per workgroup
+  int xcd_batch;               // batched launch: workgroups renumbered so that each XCD runs a contiguous run of (problem, tile)s
 };
 
 #ifdef RADNET_DIAG_STAMPS
@@ -747,6 +748,18 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
 template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<BM, BN, BMODE>()];
+  if (g.batch > 1 && g.xcd_batch) {
+    // The hardware deals workgroup L (x fastest, then y, z) to XCD L % 8, and every XCD has its own L2: the tiles of ONE problem of
+    // the batch -- which share that problem's operands (a Winograd position's filter slice is read by every row tile, its
+    // transformed input by every column tile) -- land on eight L2s and each fetches its own copy (rpn_conv1's 36 GEMMs: 306 MB
+    // fetched for 111 MB of operands).  Renumbered, XCD k runs the contiguous range [k, k + 1) * total / 8 of (problem, tile).
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), per = total >> 3;
+    const unsigned l2 = lin < (per << 3) ? (lin & 7u) * per + (lin >> 3) : lin;
+    const unsigned z = l2 / (gx * gy), r = l2 - z * gx * gy, y = r / gx;
+    conv_igemm_body<BM, BN, BMODE, SMALLC, WAVES>(g, lds, r - y * gx, y, z, gx);
+    return;
+  }
   conv_igemm_body<BM, BN, BMODE, SMALLC, WAVES>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
@@ -766,6 +779,7 @@ struct WgradArgs {
   int atomic;
   const int* rowtab;     // [taps][mpad] byte offset of the row's tap in the biased x descriptor, or kOOB; see get_row_table
   int mpad;              // M rounded up to whole 32-row tiles
+  int xcd_batch;         // batched launch: XCD-contiguous workgroup numbering (GemmArgs::xcd_batch)
   unsigned x_bias;       // bytes the x descriptor starts ahead of x (halo rows keep non-negative offsets)
   unsigned x_bytes, dy_bytes;
   int batch, splits;     // batch > 1: blockIdx.z = problem * splits + split (radnet_wgrad_batched)
@@ -1055,6 +1069,14 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __res
 template <int BMK, int BN>
 __global__ void __launch_bounds__(NTHREADS) conv_wgrad_kernel(WgradArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[wgrad_lds_floats<BMK, BN>()];
+  if (g.batch > 1 && g.xcd_batch) {             // see conv_igemm_kernel: the tiles of one problem share its two operands
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), per = total >> 3;
+    const unsigned l2 = lin < (per << 3) ? (lin & 7u) * per + (lin >> 3) : lin;
+    const unsigned z = l2 / (gx * gy), r = l2 - z * gx * gy, y = r / gx;
+    conv_wgrad_body<BMK, BN>(g, lds, r - y * gx, y, z);
+    return;
+  }
   conv_wgrad_body<BMK, BN>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -1290,8 +1312,9 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.units = nullptr;
     g.partial = nullptr;
     g.counters = nullptr;
-    if (g.batch > 1 && t.splits != 1) return RADNET_ERR_UNSUPPORTED;      // a batch is its own source of workgroups
-    if (t.splits > 1 || t.splits < 0) {
+    if (g.batch > 1 && t.splits != 1 && t.splits != -1) return RADNET_ERR_UNSUPPORTED;      // a batch is its own source of workgroups
+    g.xcd_batch = (g.batch > 1 && t.splits == -1) ? 1 : 0;        // -1: the same plain grid, XCD-contiguous numbering
+    if (g.batch <= 1 && (t.splits > 1 || t.splits < 0)) {
       tb = get_unit_table(ctx, g.M, g.N, g.K, t.bm, t.bn, t.splits);
       if (!tb) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv: cannot build the work-unit table");
       if ((uint64_t)tb->n_slots * t.bm * t.bn * sizeof(float) > ctx->ws_bytes) return RADNET_ERR_UNSUPPORTED;   // candidate skipped
@@ -1353,7 +1376,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       for (int s : chunks) {
         if (s > 1 && (ctx->ws == nullptr || nk / s < 2)) continue;               // slices shorter than 2 k-tiles
         for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
-          if (sign < 0 && tiles * s < 16) continue;
+          if (sign < 0 && tiles * s * (g.batch > 1 ? g.batch : 1) < 16) continue;
           for (int waves = 4; waves <= (for_pair ? 4 : 8); waves += 4) {        // 8 = K tile halved between two wave grids
             TileChoice t{cand[c][0], cand[c][1], sign * s, waves};
             float ms = 0.f;
@@ -1390,7 +1413,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   if (rc == RADNET_ERR_UNSUPPORTED && ctx->force_a <= 0) {
     // a shared / loaded / adopted choice this launch cannot use: slabs larger than THIS context's workspace, or a K-split /
     // XCD-ordered unit table for a problem that is now launched as a batch (a batch is one plain grid per problem)
-    tc.splits = g.batch > 1 ? 1 : (tc.splits < 0 ? -1 : 1);
+    tc.splits = (tc.splits < 0 ? -1 : 1);
     rc = launch(tc);
   }
   if (rc == RADNET_ERR_UNSUPPORTED)
@@ -1755,6 +1778,11 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   const int nmt = radnet_cdiv(g.M, BK);
   uint64_t wgrad_slab_bytes = 0;
   auto launch = [&](int bmk, int bn, int splits) -> int {
+    g.xcd_batch = (batch > 1 && splits < 0) ? 1 : 0;      // a batch: -s = the same grid, XCD-contiguous numbering
+    if (splits < 0) {
+      if (batch <= 1) return RADNET_ERR_UNSUPPORTED;
+      splits = -splits;
+    }
     wgrad_slab_bytes = 0;
     g.mt_per_split = radnet_cdiv(nmt, splits);
     g.splits = splits;
@@ -1818,13 +1846,15 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
       for (int cn = 128; cn >= 64; cn -= 64) {
         if (cn > 64 && g.N <= 64) continue;
         if (for_pair && cn != 64) continue;
-        for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
-          if (s > 1 && (nmt / s < 2 || radnet_cdiv(nmt, radnet_cdiv(nmt, s)) != s)) continue;
-          float ms = 0.f;
-          int rc = radnet_time_launches(ctx, [&]() { return launch(cb, cn, s); }, 3, &ms);
-          if (rc == RADNET_ERR_UNSUPPORTED) continue;      // ordered reduction: slabs larger than the workspace
-          if (rc != RADNET_OK) return rc;
-          seen.push_back(WCand{ms, cb, cn, s});
+        for (int s0 : {1, 2, 3, 4, 6, 8, 12, 16}) {
+          if (s0 > 1 && (nmt / s0 < 2 || radnet_cdiv(nmt, radnet_cdiv(nmt, s0)) != s0)) continue;
+          for (int s = s0; s >= (batch > 1 ? -s0 : s0); s -= 2 * s0) {      // a batch: also -s, the XCD-contiguous numbering
+            float ms = 0.f;
+            int rc = radnet_time_launches(ctx, [&]() { return launch(cb, cn, s); }, 3, &ms);
+            if (rc == RADNET_ERR_UNSUPPORTED) continue;      // ordered reduction: slabs larger than the workspace
+            if (rc != RADNET_OK) return rc;
+            seen.push_back(WCand{ms, cb, cn, s});
+          }
         }
       }
     }
@@ -1865,6 +1895,10 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     g.db = d->db;
     if (d->db && d->dw_accumulate == 0) RADNET_CHECK_HIP(ctx, hipMemsetAsync(d->db, 0, (size_t)g.N * sizeof(float), ctx->stream));
     int rc = launch(bmk, bn, splits);
+    if (rc == RADNET_ERR_UNSUPPORTED && splits < 0) {      // a loaded / shared choice this launch cannot use as it is
+      splits = -splits;
+      rc = launch(bmk, bn, splits);
+    }
     if (rc == RADNET_ERR_UNSUPPORTED && splits > 1) {      // a forced / shared / loaded choice whose slabs exceed THIS context's workspace
       while (rc == RADNET_ERR_UNSUPPORTED && splits > 1) {
         splits = splits > 2 ? splits / 2 : 1;

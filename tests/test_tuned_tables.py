@@ -20,9 +20,9 @@ def _valid(key, a, b, s, w):
     assert a in (64, 128) and b in (64, 128) and w in (4, 8) and s != 0 and abs(s) <= 64, (key, a, b, s, w)
     wgrad = (kind & 7) in (2, 3)
     if kind >= 8:
-        assert s == 1, (key, s)                                     # a batch is its own source of workgroups
+        assert s in (1, -1), (key, s)                               # a batch is its own source of workgroups; -1: XCD-contiguous numbering
     if wgrad:
-        assert c % a == 0 and s >= 1 and w == 4, (key, a, s, w)
+        assert c % a == 0 and (s >= 1 or kind >= 8) and w == 4, (key, a, s, w)
         nmt = (m + 31) // 32
         if s > 1:
             assert nmt // s >= 2 and -(-nmt // -(-nmt // s)) == s, (key, s)     # no empty pixel split

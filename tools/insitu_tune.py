@@ -66,6 +66,8 @@ def neighbours(key, cur):
                 for j in (range(len(WGRAD_SLICES)) if WIDE else (i - 1, i + 1, i + 2)):
                     if 0 <= j < len(WGRAD_SLICES) and ok(WGRAD_SLICES[j]):
                         out.append((a, b, WGRAD_SLICES[j], w))
+        if batched and abs(s) == 1:
+            out.append((a, b, -s, w))                      # plain / XCD-contiguous numbering of the batch's workgroups
         for ta in (64, 128):
             for tb in (64, 128):
                 if (ta, tb) != (a, b) and c % ta == 0 and not (tb > 64 and n <= 64):
@@ -86,6 +88,8 @@ def neighbours(key, cur):
         tiles = cdiv(m, a) * cdiv(n, b)
         if tiles * abs(s) >= 16:
             out.append((a, b, -s, w))                      # the other workgroup order (plain / XCD-contiguous)
+    elif abs(s) == 1:
+        out.append((a, b, -s, w))                          # batched launch: plain / XCD-contiguous numbering of its workgroups
     out.append((a, b, s, 12 - w))                          # 4 <-> 8 waves
     for ta in (64, 128):
         for tb in (64, 128):
