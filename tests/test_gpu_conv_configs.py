@@ -101,3 +101,42 @@ def test_wgrad_every_config(ctx, shape):
             ctx.check(ctx.lib.radnet_conv_wgrad(ctx.h, C.byref(d)), "wgrad %s" % ((bmk, bn, s, mode),))
             close(dw.cpu().numpy(), dw_ref.reshape(-1, cout))
     ctx.lib.radnet_force_config(ctx.h, 0, 0, 0)
+
+
+@pytest.mark.parametrize("shape", [(36, 160, 256, 256), (16, 75, 128, 96), (36, 23, 64, 64)])
+def test_batched_launches_xcd_contiguous_numbering_changes_no_bit(ctx, shape):
+    """slices = -1 on a batched launch (radnet_gemm_batched / radnet_wgrad_batched: the positions of a Winograd layer) only
+    renumbers the workgroups -- XCD k runs the k-th eighth of the (problem, tile) list -- so the results are the plain grid's
+    bit for bit, for grids that divide by 8 and grids that do not, every tile shape, 4 and 8 waves."""
+    batch, T, c, n = shape
+    rs = np.random.RandomState(sum(shape))
+    V = dev(rs.standard_normal((batch, T, c)).astype(np.float32))
+    U = dev(rs.standard_normal((batch, c, n)).astype(np.float32))
+    dZ = dev(rs.standard_normal((batch, T, n)).astype(np.float32))
+    ref = np.einsum("ptc,pcn->ptn", V.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
+    for bm, bn, wv in [(64, 64, 4), (64, 64, 8), (64, 128, 4), (128, 64, 4), (128, 128, 8)]:
+        if bn > 64 and n <= 64:
+            continue
+        out = {}
+        for s in (1, -1):
+            ctx.check(ctx.lib.radnet_force_config(ctx.h, bm, bn, s), "force")
+            ctx.check(ctx.lib.radnet_force_waves(ctx.h, wv), "waves")
+            M = torch.zeros(batch, T, n, device="cuda")
+            ctx.call("radnet_gemm_batched", V, U, M, batch, T, n, c)
+            out[s] = M.cpu().numpy()
+        assert np.array_equal(out[1], out[-1]), (shape, bm, bn, wv)
+        close(out[-1], ref)
+    ctx.check(ctx.lib.radnet_force_waves(ctx.h, 0), "waves off")
+    dref = np.einsum("ptc,ptn->pcn", V.cpu().numpy().astype(np.float64), dZ.cpu().numpy().astype(np.float64))
+    for bmk, bn in [(64, 64), (64, 128), (128, 64) if c % 128 == 0 else (64, 64)]:
+        if bn > 64 and n <= 64:
+            continue
+        out = {}
+        for s in (1, -1):
+            ctx.check(ctx.lib.radnet_force_config(ctx.h, bmk, bn, s), "force")
+            dU = torch.zeros(batch, c, n, device="cuda")
+            ctx.call("radnet_wgrad_batched", V, dZ, dU, batch, T, c, n, 0)
+            out[s] = dU.cpu().numpy()
+        assert np.array_equal(out[1], out[-1]), (shape, bmk, bn)
+        close(out[-1], dref)
+    ctx.lib.radnet_force_config(ctx.h, 0, 0, 0)
