@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--start", default=None, help="table to start from instead of this process's autotuning")
     ap.add_argument("--gain", type=float, default=0.0025, help="relative step-time gain a change must show, twice")
     ap.add_argument("--wide", action="store_true", help="try every K-slice count of a shape, not only the neighbouring ones")
+    ap.add_argument("--dp-rehearsal", action="store_true", help="tune the data-parallel step's schedule (1-rank RCCL group, deferred head update)")
     ap.add_argument("--trainable", choices=("train", "cont"), default="train")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
     args = ap.parse_args()
@@ -141,9 +142,18 @@ def main():
 
         ts = _Adapter()
     else:
+        if args.dp_rehearsal:                 # the data-parallel step's schedule on ONE GPU (bench.py RADNET_BENCH_REHEARSAL=nccl1): a 1-rank
+            import torch.distributed as dist  # RCCL group, both gradient exchanges issued from their lanes, head update deferred
+            from radnet_hip import trainer as _tr
+            _tr.FORCE_COLLECTIVES = True
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29535")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         eng = make_engine(Config())
         eng.set_weights(synth.synthetic_weights(seed=3))
-        ts = TrainStep(eng)
+        ts = TrainStep(eng, defer_head_update=True if args.dp_rehearsal else None)
     batch = bench.make_batch(0, args.per_gpu_batch, 600, 1000)
     look = getattr(ts, "LOOKAHEAD", 3)
     n_prime = 2 * getattr(ts, "NBUF", 6) + 6
