@@ -1,0 +1,201 @@
+"""Launch shapes tuned IN SITU: against the throughput of the running step instead of each launch alone.
+
+The engine's autotuner (csrc/conv_mfma.hip: run_igemm / run_wgrad) times every problem shape by itself on an idle chip.  In the
+pipelined train step (trainer.TrainStep, four lanes) a launch shares the CUs with the other lanes' launches, and the shape that is
+fastest alone is not always the one that packs best (+6 % at 1000x600).  `tune()` starts from the table of the shapes
+the workload launches and walks it entry by entry: the neighbouring shapes the autotuner itself would consider (other tile, other
+K-slice count / unit order, 4- or 8-wave form), layer programs re-recorded, a few hundred steps timed; a change is kept only if the
+step got faster by more than the noise twice AND the unchanged table, measured again afterwards, still loses.  Every launch shape
+computes the same convolution (sums associate differently, nothing else), so a training job can keep training while this runs; the
+result is an ordinary tuning table (radnet_tune_save format) for engine.load_tuning / `bench.py --tune-cache` / radnet_hip/tuned/.
+
+Command line: tools/insitu_tune.py."""
+import time
+
+BK = 32
+FWD_SLICES = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16]
+WGRAD_SLICES = [1, 2, 3, 4, 6, 8, 12, 16]
+
+
+def cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def read_table(path):
+    tab, header = {}, None
+    for line in open(path):
+        if line.startswith("#"):
+            header = line
+            continue
+        f = line.split()
+        if len(f) < 11:
+            continue
+        key = tuple(int(v) for v in f[:7])
+        tab[key] = [int(f[7]), int(f[8]), int(f[9]), float(f[10]), int(f[11]) if len(f) > 11 else 4]
+    return tab, header
+
+
+def write_table(path, tab, header):
+    with open(path, "w") as f:
+        f.write(header or "# radnet tuned GEMM launch shapes v2: kind m n k c npos stride | tile_a tile_b slices ms waves\n")
+        for key in sorted(tab):
+            a, b, s, ms, w = tab[key]
+            f.write("%s %d %d %d %.6f %d\n" % (" ".join(str(v) for v in key), a, b, s, ms, w))
+
+
+WIDE = False      # --wide: every K-slice count (both unit orders) instead of the two or three next to the current one
+
+
+def neighbours(key, cur):
+    """Launch shapes next to `cur` inside the autotuner's own candidate space (conv_mfma.hip: run_igemm / run_wgrad)."""
+    kind, m, n, k, c, npos, stride = key
+    a, b, s, _, w = cur
+    out = []
+    wgrad = (kind & 7) in (2, 3)
+    batched = kind >= 8
+    if wgrad:
+        nmt = cdiv(m, BK)
+        ok = lambda v: v == 1 or (nmt // v >= 2 and cdiv(nmt, cdiv(nmt, v)) == v)
+        if not batched:
+            i = WGRAD_SLICES.index(s) if s in WGRAD_SLICES else None
+            if i is not None:
+                for j in (range(len(WGRAD_SLICES)) if WIDE else (i - 1, i + 1, i + 2)):
+                    if 0 <= j < len(WGRAD_SLICES) and ok(WGRAD_SLICES[j]):
+                        out.append((a, b, WGRAD_SLICES[j], w))
+        if batched and abs(s) == 1:
+            out.append((a, b, -s, w))                      # plain / XCD-contiguous numbering of the batch's workgroups
+        for ta in (64, 128):
+            for tb in (64, 128):
+                if (ta, tb) != (a, b) and c % ta == 0 and not (tb > 64 and n <= 64):
+                    out.append((ta, tb, s, w))
+        return [o for i, o in enumerate(out) if o != (a, b, s, w) and o not in out[:i]]
+    nk = cdiv(k, BK)
+    if not batched:
+        mag = abs(s)
+        i = FWD_SLICES.index(mag) if mag in FWD_SLICES else None
+        if i is not None:
+            for j in (range(len(FWD_SLICES)) if WIDE else (i - 1, i + 1, i + 2)):
+                if 0 <= j < len(FWD_SLICES):
+                    v = FWD_SLICES[j]
+                    if v == 1 or nk // v >= 2:
+                        out.append((a, b, v if s > 0 else -v, w))
+                        if WIDE and cdiv(m, a) * cdiv(n, b) * v >= 16:
+                            out.append((a, b, -v if s > 0 else v, w))
+        tiles = cdiv(m, a) * cdiv(n, b)
+        if tiles * abs(s) >= 16:
+            out.append((a, b, -s, w))                      # the other workgroup order (plain / XCD-contiguous)
+    elif abs(s) == 1:
+        out.append((a, b, -s, w))                          # batched launch: plain / XCD-contiguous numbering of its workgroups
+    out.append((a, b, s, 12 - w))                          # 4 <-> 8 waves
+    for ta in (64, 128):
+        for tb in (64, 128):
+            if (ta, tb) != (a, b) and not (tb > 64 and n <= 64) and not (ta > 64 and m <= 64):
+                out.append((ta, tb, s if batched else (1 if abs(s) == 1 else s), w))
+    seen, uniq = set(), []
+    for o in out:
+        if o not in seen and o != (a, b, s, w):
+            seen.add(o)
+            uniq.append(o)
+    return uniq
+
+
+
+def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, gain=0.0025, wide=False, n_prime=18, log=print):
+    """Walk `eng`'s launch-shape table against the throughput of the workload.
+
+    run(n): enqueue n steps of the workload (the caller's loop over TrainStep.step with its lookahead); flush(): drain it.
+    The engine must come without tables of its own (RADNET_SHIPPED_TUNING=0) and must not have run the workload yet: the shapes
+    it measures itself during the first n_prime steps are the shapes that are walked -- a change to a shape the workload never
+    launches can only "win" by noise.  start: path of a table whose entries for those shapes replace the measured ones first.
+    out: the table is written there after every kept change.  Returns (us_per_step_before, us_per_step_after, changes)."""
+    import torch
+    global WIDE
+    WIDE = bool(wide)
+    t_begin = time.perf_counter()
+    tmp = out + ".tmp"
+
+    def measure(n=steps):
+        run(20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    def apply(tab, header):
+        flush()
+        torch.cuda.synchronize()
+        write_table(tmp, tab, header)
+        eng.load_tuning(tmp)
+        eng._graphs.clear()                  # programs run eagerly once (unit tables are built), then are recorded again
+        run(n_prime)
+        torch.cuda.synchronize()
+
+    run(n_prime)
+    torch.cuda.synchronize()
+    eng.save_tuning(tmp)
+    tab, header = read_table(tmp)
+    if start:
+        used = set(tab)
+        start_tab, _ = read_table(start)
+        tab.update({k: v for k, v in start_tab.items() if k in used})
+        apply(tab, header)
+    best = min(measure(), measure())
+    log("start: %d entries, step %.1f us (%.1f steps/s)" % (len(tab), best, 1e6 / best))
+    start_us = best
+    changed = []
+    n_tried = 0
+    out_of_time = lambda: time.perf_counter() - t_begin > budget_s
+    for p in range(passes):
+        n_acc = 0
+        # longest launches first: ms x (how often is unknown) -- the per-launch time is the proxy
+        for key in sorted(tab, key=lambda kk: -tab[kk][3]):
+            cur = list(tab[key])
+            for cand in neighbours(key, cur):
+                if out_of_time():
+                    break
+                n_tried += 1
+                if n_tried % 25 == 0:          # the box drifts (clocks, neighbours on a shared host): refresh the figure to beat
+                    apply(tab, header)
+                    ref = min(measure(), measure())
+                    log("  reference re-measured: %.1f us (was %.1f)" % (ref, best))
+                    best = ref
+                trial = dict(tab)
+                trial[key] = [cand[0], cand[1], cand[2], cur[3], cand[3]]
+                try:
+                    apply(trial, header)
+                    t1 = measure()
+                    ok = t1 < best * (1.0 - gain)
+                    t2 = measure() if ok else t1
+                    ok = ok and t2 < best * (1.0 - gain)
+                    if ok:                     # A / B / A: the table without the change, measured again now, must still lose
+                        apply(tab, header)
+                        ref = min(measure(), measure())
+                        ok = max(t1, t2) < ref * (1.0 - gain)
+                        log("    reference now %.1f us" % ref)
+                        if not ok:
+                            best = ref
+                except RuntimeError as e:      # the step's state is unknown after a failed launch: stop with what is kept so far
+                    log("  %s -> %s: %s -- stopping" % (key, cand, str(e).splitlines()[0][:160]))
+                    write_table(out, tab, header)
+                    raise
+                log("  %-44s %s -> %s : %.1f / %.1f us vs %.1f %s" % (key, tuple(cur[:3] + [cur[4]]), cand, t1, t2, best, "KEPT" if ok else ""))
+                if ok:
+                    tab = trial
+                    cur = list(tab[key])
+                    best = max(t1, t2)
+                    n_acc += 1
+                    changed.append((key, cand))
+                    write_table(out, tab, header)
+            if out_of_time():
+                log("budget reached")
+                break
+        log("pass %d: %d changes kept, step %.1f us" % (p + 1, n_acc, best))
+        if n_acc == 0 or out_of_time():
+            break
+    apply(tab, header)
+    end_us = min(measure(2 * steps), measure(2 * steps))
+    write_table(out, tab, header)
+    import os
+    os.remove(tmp)
+    return start_us, end_us, changed

@@ -1,6 +1,5 @@
 """Shipped launch-shape tables (radnet_hip/tuned/) and the in-situ tuner's candidate generator: host logic, no GPU."""
 import glob
-import importlib.util
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,10 +7,10 @@ TUNED = os.path.join(ROOT, "rock-art-radnet_amd", "radnet_hip", "tuned")
 
 
 def _tool():
-    spec = importlib.util.spec_from_file_location("insitu_tune", os.path.join(ROOT, "tools", "insitu_tune.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "rock-art-radnet_amd"))
+    from radnet_hip import insitu
+    return insitu
 
 
 def _valid(key, a, b, s, w):
