@@ -3,7 +3,7 @@ instead of each launch alone -- for one of bench.py's workloads, and write the t
 --tune-cache`, engine.load_tuning, radnet_hip/tuned/).  2-4 minutes per pass on one MI355X.
 
 usage: python tools/insitu_tune.py <out table> [--passes 1] [--steps 200] [--budget-s 900] [--start <table>] [--wide]
-                                   [--per-gpu-batch 1] [--trainable train|cont] [--dp-rehearsal]"""
+                                   [--per-gpu-batch 1] [--trainable train|cont] [--dp-rehearsal] [--workload train|predict]"""
 import argparse
 import os
 import sys
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--wide", action="store_true", help="try every K-slice count of a shape, not only the neighbouring ones")
     ap.add_argument("--dp-rehearsal", action="store_true", help="tune the data-parallel step's schedule (1-rank RCCL group, deferred head update)")
     ap.add_argument("--trainable", choices=("train", "cont"), default="train")
+    ap.add_argument("--workload", choices=("train", "predict"), default="train", help="predict = RADNet.predict's tile loop (cfg 3)")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
     args = ap.parse_args()
     os.environ["RADNET_SHIPPED_TUNING"] = "0"      # start from what the engine measures itself (or --start), never from a shipped table
@@ -31,6 +32,29 @@ def main():
     from faster_rcnn.config import Config
     from radnet_hip import insitu, make_engine, synth
     from radnet_hip.trainer import TrainStep
+    if args.workload == "predict":         # RADNet.predict's tile loop (BASELINE cfg 3): 2048x2048 tiles, two in flight (RADNet._detect_all)
+        import numpy as np
+        from faster_rcnn import models as M
+        from faster_rcnn.RADNet import RADNet
+        from faster_rcnn.base_models import resnet50
+        C = Config()
+        m_rpn, m_cls, m_all, m_rpn3, m_det = M.build_models(C, weights=synth.synthetic_weights(seed=3))
+        net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+        net.device_resident = True
+        eng = m_rpn3._s.eng
+        tiles = [np.random.RandomState(40 + i).randint(0, 256, (2048, 2048, 3)).astype(np.uint8) for i in range(8)]
+
+        def run(n):
+            while n > 0:
+                net._detect_all(tiles[:max(2, min(n, len(tiles)))])
+                n -= len(tiles)
+
+        before, after, changed = insitu.tune(eng, run, lambda: None, args.out, passes=args.passes, steps=args.steps, budget_s=args.budget_s,
+                                             start=args.start, gain=args.gain, wide=args.wide, n_prime=8, log=lambda m: print(m, flush=True))
+        print("in situ: tile %.1f -> %.1f us (%.1f -> %.1f tiles/s), %d entries changed" % (before, after, 1e6 / before, 1e6 / after, len(changed)))
+        for key, cand in changed:
+            print("  changed %s -> tile %dx%d slices %d waves %d" % (key, cand[0], cand[1], cand[2], cand[3]))
+        return
     if args.trainable == "cont":           # cont_train.py mode: stages 3-4 train in both models, one lane (bench.py --trainable cont)
         from radnet_hip.engine_cont import ContEngine
         from radnet_hip.trainer_cont import ContTrainStep
