@@ -3,7 +3,7 @@ instead of each launch alone -- for one of bench.py's workloads, and write the t
 --tune-cache`, engine.load_tuning, radnet_hip/tuned/).  2-4 minutes per pass on one MI355X.
 
 usage: python tools/insitu_tune.py <out table> [--passes 1] [--steps 200] [--budget-s 900] [--start <table>] [--wide]
-                                   [--per-gpu-batch 1] [--trainable train|cont] [--dp-rehearsal] [--workload train|predict]"""
+                                   [--per-gpu-batch 1] [--trainable train|cont] [--dp-rehearsal] [--workload train|predict] [--network resnet50|vgg16]"""
 import argparse
 import os
 import sys
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--wide", action="store_true", help="try every K-slice count of a shape, not only the neighbouring ones")
     ap.add_argument("--dp-rehearsal", action="store_true", help="tune the data-parallel step's schedule (1-rank RCCL group, deferred head update)")
     ap.add_argument("--trainable", choices=("train", "cont"), default="train")
+    ap.add_argument("--network", choices=("resnet50", "vgg16"), default="resnet50")
     ap.add_argument("--workload", choices=("train", "predict"), default="train", help="predict = RADNet.predict's tile loop (cfg 3)")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
     args = ap.parse_args()
@@ -80,8 +81,12 @@ def main():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(0)
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        eng = make_engine(Config())
-        eng.set_weights(synth.synthetic_weights(seed=3))
+        C = Config()
+        if args.network == "vgg16":           # BASELINE cfg 5: VGG16 base, 3 scales x 3 ratios, fc head
+            C.network, C.anchor_box_scales = "vgg16", [128, 256, 512]
+        eng = make_engine(C)
+        eng.set_weights(synth.synthetic_weights_vgg16(seed=3, n_anchors=eng.A, n_classes=eng.nc) if args.network == "vgg16"
+                        else synth.synthetic_weights(seed=3))
         ts = TrainStep(eng, defer_head_update=True if args.dp_rehearsal else None)
     batch = bench.make_batch(0, args.per_gpu_batch, 600, 1000)
     look = getattr(ts, "LOOKAHEAD", 3)
