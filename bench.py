@@ -97,6 +97,23 @@ def _time_us(fn, n=30, warm=5):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def _time_graph_us(eng, ops, reps=8, n=20):
+    """Per-pass time of a launch list replayed the way the step launches it: `reps` passes recorded into ONE hipGraph (engine._run:
+    eager first, captured on the second call), replayed n times between two events on the launch stream -- kernels back to back with
+    no host launch latency between them (a ctypes call per kernel costs 5-10 us of host time, more than some of these kernels last)."""
+    prog = list(ops) * reps
+    eng._run(prog)
+    eng._run(prog)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        eng._run(prog)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (n * reps)
+
+
 def committed_pmc_traffic():
     """HBM bytes per launch of the dominant GEMM kernel from the committed PMC passes of this same command
     (profiles/r03_pmc_summary_insitu_tables.txt, else the earlier ones: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
@@ -172,14 +189,23 @@ def layers_3x3_table(eng, bp, rp):
             w_in(h, x, nb, hh, ww, cin, V)
             gemm(h, V, U, M, P, T, n, cin)
             w_out(h, M, nb, hh, ww, n, scale, shift, act, y, ldy)
-        t_layer = _time_us(layer)
+        t_layer_stream = _time_us(layer)
         d, _, _ = eng._desc(c, _Ptr(x), nb, hh, ww, _Ptr(y), relu=bool(act))
-        t_dir = _time_us(lambda: lib.radnet_conv_fwd(h, C.byref(d)))
+        t_dir_stream = _time_us(lambda: lib.radnet_conv_fwd(h, C.byref(d)))
+        # the figures the fractions use: the layer as the step launches it (hipGraph replay, kernels back to back)
+        try:
+            t_layer = _time_graph_us(eng, [("wino", found[name])])
+            t_dir = _time_graph_us(eng, [("conv", d)])
+        except Exception:                                  # graphs switched off / capture failed: the stream-launch figures
+            t_layer, t_dir = t_layer_stream, t_dir_stream
         algo = 2.0 * nb * hh * ww * n * 9 * cin
         execd = 2.0 * P * T * cin * n
         rows.append({"layer": label, "M": nb * hh * ww, "N": n, "K": 9 * cin, "tiles": T, "winograd_form": "F(%dx%d,3x3)" % (form, form),
-                     "winograd_us": {"input_transform": t_in, "gemm_batched": t_g, "gemms": P, "output_transform": t_out, "layer_back_to_back": t_layer},
-                     "direct_us": t_dir, "algorithmic_gflop": algo / 1e9, "winograd_executed_gflop": execd / 1e9,
+                     "winograd_us": {"input_transform": t_in, "gemm_batched": t_g, "gemms": P, "output_transform": t_out, "layer_back_to_back": t_layer,
+                                     "layer_stream_launches": t_layer_stream,
+                                     "how": "layer_back_to_back / direct_us: 8 passes in one hipGraph (as the step launches its programs), replayed; "
+                                            "the three parts and layer_stream_launches: one host launch per kernel, 30 in a row"},
+                     "direct_us": t_dir, "direct_stream_launches_us": t_dir_stream, "algorithmic_gflop": algo / 1e9, "winograd_executed_gflop": execd / 1e9,
                      "winograd_gemm_executed_tflops": execd / t_g / 1e6, "winograd_gemm_executed_frac": execd / t_g / 1e6 / PEAK_FP32_MFMA_TFLOPS,
                      "winograd_layer_algorithmic_tflops": algo / t_layer / 1e6, "winograd_layer_algorithmic_frac": algo / t_layer / 1e6 / PEAK_FP32_MFMA_TFLOPS,
                      "direct_tflops": algo / t_dir / 1e6, "direct_frac": algo / t_dir / 1e6 / PEAK_FP32_MFMA_TFLOPS})

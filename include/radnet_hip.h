@@ -354,20 +354,26 @@ int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops);
 /* ---- a run of dependent layers as ONE persistent launch ("chain"; resnet50.py:150-228 nn_base, stages 2-4) --------------
  * radnet_chain_build turns a list of CONV_FWD (channels a multiple of 32) and WINO (form 4) ops -- the same radnet_op[] that
  * radnet_program_run would launch one by one -- into a list of work items (output tiles, transform blocks) in dependency
- * order plus arrival counters; radnet_chain_run launches `workgroups` persistent workgroups (0: two per CU) that draw the
- * items and start each as soon as the blocks it reads are complete.  Same kernels' code, same arithmetic per output element
+ * order plus arrival counters; radnet_chain_run launches `workgroups` persistent workgroups (0: two per CU; at most 4 per CU)
+ * among which the items are dealt statically (workgroup b: items b, b + grid, ...) and which start each item as soon as the
+ * blocks it reads are complete.  The deal is deadlock-free only while EVERY workgroup of the grid is resident -- of every chain
+ * running at the same time: callers that run chains side by side divide the 4 x 256 slots between them (the engine does).  Same kernels' code, same arithmetic per output element
  * as the launches it replaces for the convs (64x64 tiles; K-split layers add their slices in slice order); what goes away
  * is the gap between dependent launches, their lockstep prologue / epilogue phases and their tails.  A narrow
  * grid leaves CU slots to launches on other streams.  RADNET_ERR_UNSUPPORTED for an op the chain cannot run: the caller
  * keeps radnet_program_run.  The chain holds device memory of its own (items, counters, K-split slabs): build it outside
  * stream capture; radnet_chain_run allocates nothing and can be captured.  radnet_chain_status synchronises the stream;
- * last_error != 0: a workgroup waited ~seconds for an input block that never completed (1 + item index; the launch still
- * drains and can be replayed, its outputs are invalid). */
+ * last_error != 0: a workgroup waited 1 s for an input block that never completed (1 + item index; the launch still
+ * drains, its outputs are INVALID).  The first such error is sticky and also lands in a mapped host word: radnet_chain_error
+ * reads it without synchronising (0 = none so far; a launch still in flight may yet fail), and radnet_chain_run refuses
+ * (RADNET_ERR_HIP) to launch a chain that has failed before.  Every tensor of the list must be written once and never after it
+ * has been read (no buffer re-use inside a chain): radnet_chain_build / radnet_chain_check refuse such a list. */
 typedef struct radnet_chain radnet_chain;
 int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t n_ops, int32_t workgroups, radnet_chain** out);
 int radnet_chain_run(radnet_ctx* ctx, radnet_chain* chain);
 int radnet_chain_status(radnet_ctx* ctx, radnet_chain* chain, int32_t* last_error, int32_t* runs, int32_t* n_items, int32_t* n_stages,
                         double* flops_executed, double* flops_algorithmic);
+uint32_t radnet_chain_error(radnet_chain* chain);
 void radnet_chain_destroy(radnet_chain* chain);
 /* Diagnosis while a chain launch runs (uses a stream of its own): out[0..7] = {next item, workgroups gone, error, first
  * error, runs, ...}; with item >= 0, out[8..19] = its record {stage, bx, by, bz, dep0 first, dep0 count, dep1 first, dep1 count,
@@ -376,7 +382,7 @@ void radnet_chain_destroy(radnet_chain* chain);
 int radnet_chain_peek(radnet_chain* chain, int32_t item, uint32_t* out, int32_t out_words);
 /* Host-only (no device, no context): plans the work-item list of `ops` as radnet_chain_build would and checks that it can
  * run in list order -- every item finds its input blocks completed by earlier items, every counter reaches exactly the
- * count its waiters expect -- which is what makes the launch deadlock-free for any number of workgroups.  first_bad_item:
+ * count its waiters expect -- which is what makes the launch deadlock-free while its workgroups are all resident.  first_bad_item:
  * -1, or the offending item (n_items: a counter that never reaches its count).  The pointers in `ops` are used as
  * identities only.  radnet_chain_build runs the same check and refuses a list that fails it. */
 int radnet_chain_check(const radnet_op* ops, int32_t n_ops, int32_t* n_items, int32_t* n_stages, int32_t* n_counters, int32_t* first_bad_item,

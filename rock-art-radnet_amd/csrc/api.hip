@@ -108,7 +108,10 @@ extern "C" int radnet_tune_load(radnet_ctx* ctx, const char* path) {
     if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %lf %d", &k.kind, &k.m, &k.n, &k.k, &k.c, &k.npos, &k.stride, &t.a, &t.b, &t.splits, &ms,
                &waves) < 11) continue;
     t.waves = waves == 8 ? 8 : 4;
-    if ((t.a != 64 && t.a != 128) || (t.b != 64 && t.b != 128) || t.splits == 0 || t.splits > 64 || t.splits < -64) continue;
+    // tiles: 64 / 128; the forward / data-gradient kernel (kinds 0, 1, 8) also has 32x64 and 32x32 in its 4-wave form
+    const bool small_ok = (k.kind & 2) == 0 && t.waves == 4 && t.a == 32 && (t.b == 32 || t.b == 64);
+    if (!small_ok && ((t.a != 64 && t.a != 128) || (t.b != 64 && t.b != 128))) continue;
+    if (t.splits == 0 || t.splits > 64 || t.splits < -64) continue;
     t.ms = (float)ms;
     (*ctx->tuned)[k] = t;
     ++n;
@@ -119,8 +122,9 @@ extern "C" int radnet_tune_load(radnet_ctx* ctx, const char* path) {
 
 extern "C" int radnet_force_config(radnet_ctx* ctx, int tile_a, int tile_b, int slices) {
   if (!ctx) return RADNET_ERR_ARG;
-  if (tile_a != 0 && ((tile_a != 64 && tile_a != 128) || (tile_b != 64 && tile_b != 128)))
-    RADNET_FAIL(ctx, RADNET_ERR_ARG, "force_config: tiles must be 64 or 128");
+  const bool small_ok = tile_a == 32 && (tile_b == 32 || tile_b == 64);      // forward / data-gradient launches only
+  if (tile_a != 0 && !small_ok && ((tile_a != 64 && tile_a != 128) || (tile_b != 64 && tile_b != 128)))
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "force_config: tiles must be 64 or 128 (or 32x64 / 32x32)");
   ctx->force_a = tile_a;
   ctx->force_b = tile_b;
   ctx->force_splits = slices;

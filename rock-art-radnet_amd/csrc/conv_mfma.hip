@@ -29,6 +29,8 @@
 #include "radnet_internal.h"
 #include "radnet_wino4.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
+#include <set>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,6 +80,7 @@ struct GemmArgs {
   unsigned* counters;          // K-split launches: arrival counter per output tile (zero outside a launch)
   unsigned long long* stamps;  // diagnostic build only (RADNET_DIAG_STAMPS): 8 words per workgroup
   int xcd_batch;               // batched launch: workgroups renumbered so that each XCD runs a contiguous run of (problem, tile)s
+  int zper;                    // persistent batched launch (PERSIST kernels): consecutive problems one workgroup runs, blockIdx.z = group
 };
 
 #ifdef RADNET_DIAG_STAMPS
@@ -265,19 +268,38 @@ __device__ __forceinline__ void mfma_tile_rows(const float* sA, const float* sB,
 // LDS floats of one workgroup of conv_igemm_body (two buffers of an A and a B tile)
 template <int BM, int BN, int BMODE>
 constexpr int igemm_lds_floats() { return 2 * (BM * kRowPitch + ((BMODE == 0) ? BK * (BN + 4) : BN * kRowPitch)); }
+// PERSIST kernels sum their K parts while the staging buffers already hold the next problem's first tile: own scratch behind them
+template <int BM, int BN, int WAVES>
+constexpr int igemm_persist_scratch_floats() {
+  constexpr int WG = (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1), KH = WAVES / WG;
+  return (KH - 1) * BM * BN;
+}
 
 // COH: the output is handed to other workgroups of the SAME launch (chain kernel): stores are write-through (sc1), as the
 // split-K slabs are, so that a consumer on another XCD finds them in memory.
-template <int BM, int BN, int BMODE, bool SMALLC, int WAVES, bool COH = false>
+// PERSIST (batched launches, forward form, plain epilogue): the workgroup runs g.zper CONSECUTIVE problems of the batch on its output
+// tile as one long K loop -- the loads of the next problem's first K tiles are issued under the last MFMA steps of the current one,
+// the finished accumulators leave with fire-and-forget stores, and the workgroup pays ONE prologue and ONE drain instead of one per
+// problem.  The 36 GEMMs of a Winograd layer have 4-8 K tiles each: as 432-720 one-tile workgroups they were all prologue and
+// epilogue.
+template <int BM, int BN, int BMODE, bool SMALLC, int WAVES, bool COH = false, bool PERSIST = false>
 __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __restrict__ lds, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
                                                 const unsigned grid_x) {
   constexpr int NT = 64 * WAVES;
-  constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave in each direction
+  // Wave grid over the output tile: 2x2 for tiles of 64 rows / columns and more, a single wave row (column) for the 32-row
+  // (32-column) tiles; the waves left over split every 32-deep K tile between them (KH parts: the 8-wave form of the 64x64
+  // tile has KH = 2, the 4-wave 32x64 tile too, the 4-wave 32x32 tile KH = 4) and are summed through LDS after the loop.
+  constexpr int WM = BM >= 64 ? 2 : 1, WN = BN >= 64 ? 2 : 1, WG = WM * WN;
+  constexpr int KH = WAVES / WG;
+  static_assert(WAVES % WG == 0 && (KH == 1 || KH == 2 || KH == 4), "wave count does not cover the tile's wave grid");
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);     // 32x32 tiles per wave in each direction
   constexpr int PB = BN + 4;                    // forward weights: k-major [BK][PB]
   constexpr int A_ITERS = BM * 8 / NT;          // float4 chunks per thread (A)
   constexpr int B_ITERS = BN * 8 / NT;
+  static_assert(A_ITERS >= 1 && B_ITERS >= 1 && A_ITERS * NT == BM * 8 && B_ITERS * NT == BN * 8, "tile too small for this many threads");
   constexpr int kRowStep = NT / 8;              // rows between a thread's consecutive chunks
-  constexpr int kStepsW = (BK / 2) / (WAVES / 4);   // MFMA steps of one wave per K tile
+  constexpr int kStepsW = (BK / 2) / KH;        // MFMA steps of one wave per K tile
+  constexpr int kKPart = BK / KH;               // depth of a wave's part of the K tile
   // one LDS buffer: A row-major [BM][kRowPitch]; B k-major [BK][PB] (forward) or row-major [BN][kRowPitch] (dgrad)
   constexpr int kBufA = BM * kRowPitch;
   constexpr int kBufB = (BMODE == 0) ? BK * PB : BN * kRowPitch;
@@ -292,8 +314,9 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
-  const int khalf = wave >> 2;                  // 0 for 4-wave workgroups
+  const int wgi = wave % WG;                    // place in the wave grid
+  const int wm = wgi / WN, wn = wgi % WN;
+  const int khalf = wave / WG;                  // which part of every K tile (0 when the wave grid takes all waves)
   // Work assignment.  Plain launch: one workgroup per output tile.  Unit-table launch (g.units != null): the host
   // cut the linearised (tile, k-tile) iteration space into near-equal chunks so every CU gets the same amount of
   // MFMA work whatever the tile count (stream-K style); a unit is (tile, k range, partial slot or -1).
@@ -372,8 +395,11 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
   }
 
   const int nk_total = (g.K + BK - 1) / BK;
+  // batched launch (radnet_gemm_batched): problem blockIdx.z of a strided batch, same geometry; PERSIST: problems bz .. bz + nz - 1
+  const long long bz = g.batch > 1 ? (long long)bid_z * (PERSIST ? g.zper : 1) : 0;
+  const int nz = PERSIST ? ((int)bz + g.zper <= g.batch ? g.zper : g.batch - (int)bz) : 1;
   const int kt_begin = g.units != nullptr ? unit_kb : 0;
-  const int kt_end = g.units != nullptr ? unit_ke : nk_total;
+  const int kt_end = g.units != nullptr ? unit_ke : nk_total * nz;
 
   // running position of the current K tile: kernel position pos = (kh, kw) and first channel ci0, k0 = pos*C + ci0
   int pos = 0, ci0 = 0, kh_run = 0, kw_run = 0;
@@ -385,10 +411,11 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
     kw_run = pos - kh_run * g.KW;
   }
 
-  // batched launch (radnet_gemm_batched): problem blockIdx.z of a strided batch, same geometry
-  const long long bz = g.batch > 1 ? (long long)bid_z : 0;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(g.x + bz * g.x_bstride) - a_bias, g.x_bytes ? g.x_bytes + a_bias : 0u);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w + bz * g.w_bstride, g.w_bytes);
+  // (PERSIST: the descriptors span the nz problems; rows past M and columns past N are out of range through their per-lane kOOB bit,
+  // not through the extent, and K has no ragged tile -- the launcher checks C % BK == 0)
+  const unsigned span_x = PERSIST ? (unsigned)((nz - 1) * g.x_bstride * 4) : 0u, span_w = PERSIST ? (unsigned)((nz - 1) * g.w_bstride * 4) : 0u;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(g.x + bz * g.x_bstride) - a_bias, g.x_bytes ? g.x_bytes + a_bias + span_x : 0u);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.w + bz * g.w_bstride, g.w_bytes + span_w);
   const bool has_in_scale = g.in_scale != nullptr;
   const __amdgpu_buffer_rsrc_t rscale = make_rsrc(g.in_scale, has_in_scale ? (unsigned)g.C * 4u : 0u);
   // Two register stages: the loads of tile t+2 are issued while tile t is being multiplied and tile t+1 waits in the
@@ -410,6 +437,8 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
   int t_kt = 0, t_kh = 0, t_kw = 0, t_fpos = 0, t_aoff = 0;
   bool t_live = false, t_kv = false;
   unsigned s_a = kOOB, s_b = kOOB, s_sh = 0;       // wave-uniform: SGPR offsets of the tile's A / B loads, tap -> bit-31 shift
+  unsigned p_item_a = 0u, p_item_b = 0u;           // PERSIST: byte offset of the running problem in the spanning descriptors
+  int p_kin = 0;                                   //          K tile inside the running problem
 
   auto tile_begin = [&](int kt, bool live, Stage& st) {
     t_kt = kt;
@@ -423,9 +452,9 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
     } else {
       // K = npos * C and C is a multiple of BK (launcher): a live tile lies inside one tap, all of its k are valid
       t_fpos = g.flip ? (g.npos - 1 - pos) : pos;
-      s_a = live ? (unsigned)(((kh_run * g.W + kw_run) * g.C + ci0) * 4) : kOOB;
+      s_a = live ? (unsigned)(((kh_run * g.W + kw_run) * g.C + ci0) * 4) + p_item_a : kOOB;
       s_sh = (unsigned)(31 - pos);
-      s_b = !live ? kOOB : BMODE == 0 ? (unsigned)kt * (unsigned)b_tile_bytes
+      s_b = !live ? kOOB : BMODE == 0 ? (PERSIST ? (unsigned)p_kin * (unsigned)b_tile_bytes + p_item_b : (unsigned)kt * (unsigned)b_tile_bytes)
                                       : ((unsigned)t_fpos * (unsigned)g.cin_fwd * (unsigned)g.ldw + (unsigned)ci0) * 4u;
       // raw value; consumed (and replaced by 1 when there is no in_scale: empty descriptor, reads 0) only at the LDS
       // store one tile later -- touching it here would make the wave wait for the load it has just issued
@@ -434,11 +463,17 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
       ci0 += BK;
       const bool wrap = ci0 >= g.C;
       ci0 = wrap ? 0 : ci0;
-      pos += wrap ? 1 : 0;
-      kw_run += wrap ? 1 : 0;
-      const bool wrap_w = kw_run >= g.KW;
-      kw_run = wrap_w ? 0 : kw_run;
-      kh_run += wrap_w ? 1 : 0;
+      if (PERSIST) {                           // a 1x1 problem ends where its channels end: the next tile is the next problem's first
+        p_kin = wrap ? 0 : p_kin + 1;
+        p_item_a += wrap ? (unsigned)(g.x_bstride * 4) : 0u;
+        p_item_b += wrap ? (unsigned)(g.w_bstride * 4) : 0u;
+      } else {
+        pos += wrap ? 1 : 0;
+        kw_run += wrap ? 1 : 0;
+        const bool wrap_w = kw_run >= g.KW;
+        kw_run = wrap_w ? 0 : kw_run;
+        kh_run += wrap_w ? 1 : 0;
+      }
     }
   };
 
@@ -519,8 +554,8 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
 #endif
     // fragment offsets (see mfma_tile_rows): row-major operands start at (row, k = 4*hi), the k-major one at row 4*hi
     // (8-wave workgroups: waves 4-7 start at k = 16 of the tile)
-    const int a_off = (wm * (BM / 2) + l31) * kRowPitch + 4 * hi + 16 * khalf;
-    const int b_off = (BMODE == 0) ? (4 * hi + 16 * khalf) * PB + wn * (BN / 2) + l31 : (wn * (BN / 2) + l31) * kRowPitch + 4 * hi + 16 * khalf;
+    const int a_off = (wm * (BM / WM) + l31) * kRowPitch + 4 * hi + kKPart * khalf;
+    const int b_off = (BMODE == 0) ? (4 * hi + kKPart * khalf) * PB + wn * (BN / WN) + l31 : (wn * (BN / WN) + l31) * kRowPitch + 4 * hi + kKPart * khalf;
     // invariant at the top of step(kt, buf): LDS buffer `buf` holds tile kt; stage `nxt` holds tile kt+1 (in flight or
     // landed); stage `cur` is free.  MFMA steps 0 .. kLoadOps-1 each carry one global load of tile kt+2, the steps
     // after them (all but the last, which has no MFMA behind it to hide under) the LDS stores of tile kt+1.
@@ -558,11 +593,73 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
       __syncthreads();
 #endif
     };
+    // PERSIST: a problem's last K tile has been multiplied -- its sums leave while the next problem's first tile sits in the other
+    // LDS buffer and its second is in flight (nothing here waits for memory: plain stores, the K-part sums through LDS scratch of
+    // their own; the scratch is rewritten one barrier-terminated step later at the earliest)
+    [[maybe_unused]] int p_done = 0, p_out = 0;
+    auto item_flush = [&]() {
+#pragma unroll
+      for (int c = 1; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) accs[0][i][j] += accs[c][i][j];
+      if (KH > 1) {
+        constexpr int kPartFloats = WG * TM * TN * 16 * 64;
+        float* red = lds + igemm_lds_floats<BM, BN, BMODE>() + (wgi * TM * TN * 16) * 64 + lane;
+        if (khalf > 0) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) red[(khalf - 1) * kPartFloats + ((i * TN + j) * 16 + r) * 64] = accs[0][i][j][r];
+        }
+        __syncthreads();
+        if (khalf == 0) {
+#pragma unroll
+          for (int h = 1; h < KH; ++h)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[0][i][j][r] += red[(h - 1) * kPartFloats + ((i * TN + j) * 16 + r) * 64];
+        }
+      }
+      const __amdgpu_buffer_rsrc_t ryp = make_rsrc(g.y + (bz + p_out) * g.y_bstride, g.y_bytes);
+      const unsigned ldy4p = (unsigned)g.ldy * 4u;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * hi;
+          const unsigned vy = (khalf == 0 && n < g.N && mb < g.M) ? ((unsigned)mb * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) buf_store1(ryp, vy + (unsigned)((r & 3) + 8 * (r >> 2)) * ldy4p, accs[0][i][j][r]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
+      ++p_out;
+    };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
       step(kt, 0, st0, st1);
-      if (kt + 1 < kt_end) step(kt + 1, 1, st1, st0);
+      if (PERSIST && ++p_done == nk_total) { item_flush(); p_done = 0; }
+      if (kt + 1 < kt_end) {
+        step(kt + 1, 1, st1, st0);
+        if (PERSIST && ++p_done == nk_total) { item_flush(); p_done = 0; }
+      }
     }
   }
+  if (PERSIST) return;                  // every problem's tile has been stored
   f32x16(&acc)[TM][TN] = accs[0];
 #pragma unroll
   for (int c = 1; c < CH; ++c)
@@ -574,24 +671,28 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
   // through the (now free) staging array and take no further part in the output -- every global access below is
   // predicated on live_out (offset kOOB otherwise), the barriers are reached by all eight waves.
   bool live_out = true;
-  if (WAVES == 8) {
-    float* red = lds + ((wave & 3) * TM * TN * 16) * 64 + lane;
-    if (khalf == 1) {
+  if (KH > 1) {
+    static_assert((KH - 1) * WG * TM * TN * 16 * 64 <= igemm_lds_floats<BM, BN, BMODE>(), "K-part sums do not fit the staging array");
+    constexpr int kPartFloats = WG * TM * TN * 16 * 64;
+    float* red = lds + (wgi * TM * TN * 16) * 64 + lane;
+    if (khalf > 0) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) red[(khalf - 1) * kPartFloats + ((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
     }
     __syncthreads();
     if (khalf == 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int h = 1; h < KH; ++h)            // parts added in k order
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64];
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(h - 1) * kPartFloats + ((i * TN + j) * 16 + r) * 64];
     }
     __syncthreads();
     live_out = khalf == 0;
@@ -626,7 +727,7 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
     // here: each release writes back the XCD's whole L2).  Correct for any placement of the slices on XCDs / CUs.
     // Slab layout is private to this kernel: each lane keeps the 16 registers of a 32x32 accumulator contiguous
     // (64 bytes), so a slab moves with four 16-byte accesses per accumulator instead of sixteen 4-byte ones.
-    const unsigned lane_off = live_out ? (unsigned)(((wave & 3) * TM * TN * 64 + lane) * 16) * 4u : kOOB;
+    const unsigned lane_off = live_out ? (unsigned)((wgi * TM * TN * 64 + lane) * 16) * 4u : kOOB;
     const __amdgpu_buffer_rsrc_t rslab = make_rsrc(g.partial + (size_t)slot * (BM * BN), BM * BN * 4u);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -698,51 +799,87 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
   const __amdgpu_buffer_rsrc_t rmask = make_rsrc(g.mask, g.mask ? g.mask_bytes : 0u);
   const bool has_mask = g.mask != nullptr;
   const unsigned ldy4 = (unsigned)g.ldy * 4u, lda4 = (unsigned)g.ld_add * 4u, ldm4 = (unsigned)g.ld_mask * 4u;
+  // Round 4: straight-line code.  The first form tested `has_mask`, `act == 1`, `act == 2 && n < act_cols` per accumulator
+  // register: the compiler kept them as branches -- 16 x (two scalar branches, a re-load of the kernel arguments with its wait,
+  // for the mask an s_waitcnt vmcnt(0) per row) per 32x32 tile.  Now everything wave-uniform is decided once: the per-column
+  // factors come through descriptors (null -> 0, replaced by 1 / 0 with a select), ReLU is a select on a uniform flag, the
+  // sigmoid columns (rpn_out_class only) are a copy of the loop under ONE uniform branch, the mask exists in the dgrad form only.
+  const bool has_scale = g.scale != nullptr, relu = g.act == 1;
+  const __amdgpu_buffer_rsrc_t rsc = make_rsrc(g.scale, has_scale ? (unsigned)g.N * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rsh = make_rsrc(g.shift, g.shift ? (unsigned)g.N * 4u : 0u);
+  float scv[TN], shv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
-    const bool nv = n < g.N;
-    float sc = 1.f, sh = 0.f;
-    if (nv) {
-      if (g.scale) sc = g.scale[n];
-      if (g.shift) sh = g.shift[n];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * hi;
-      const bool col_ok = live_out & nv & (mb < g.M);        // mb >= M: every row of this lane is past the end
-      const unsigned vy = col_ok ? ((unsigned)mb * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB;
-      const unsigned va = col_ok ? ((unsigned)mb * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB;
-      const unsigned vm = col_ok ? ((unsigned)mb * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB;
-      float ad[16], mk[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#ifdef RADNET_DIAG_SKIP_EPILOGUE                 // measurement only: 1 of 16 rows is loaded / stored
-        if (r != 0) { ad[r] = 0.f; mk[r] = 1.f; continue; }
-#endif
-        const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
-        ad[r] = buf_load1s(radd, va, row * lda4);
-        mk[r] = 1.f;
-        if (has_mask) mk[r] = buf_load1s(rmask, vm, row * ldm4);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
-        float v = acc[i][j][r] * sc + sh + ad[r];
-        if (!(mk[r] > 0.f)) v = 0.f;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2 && n < g.act_cols) v = 1.f / (1.f + __expf(-v));
-#ifdef RADNET_DIAG_SKIP_EPILOGUE
-        if (r != 0) { asm volatile("" ::"v"(v)); continue; }
-#endif
-        if (COH) buf_store1_sc1(ry, vy + row * ldy4, v);
-        else buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
-      }
-    }
+    const int n = n0 + wn * (BN / WN) + j * 32 + l31;
+    const unsigned off = n < g.N ? (unsigned)n * 4u : kOOB;
+    scv[j] = buf_load1(rsc, off);
+    shv[j] = buf_load1(rsh, off);
   }
+  auto out_tiles = [&](auto sig_tag) {
+    constexpr bool SIG = decltype(sig_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * 32 + l31;
+      const bool nv = n < g.N;
+      const float sc = has_scale ? scv[j] : 1.f, sh = shv[j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * hi;
+        const bool col_ok = live_out & nv & (mb < g.M);        // mb >= M: every row of this lane is past the end
+        const unsigned vy = col_ok ? ((unsigned)mb * (unsigned)g.ldy + (unsigned)n) * 4u : kOOB;
+        const unsigned va = col_ok ? ((unsigned)mb * (unsigned)g.ld_add + (unsigned)n) * 4u : kOOB;
+        const unsigned vm = col_ok ? ((unsigned)mb * (unsigned)g.ld_mask + (unsigned)n) * 4u : kOOB;
+        float ad[16], mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifdef RADNET_DIAG_SKIP_EPILOGUE                 // measurement only: 1 of 16 rows is loaded / stored
+          if (r != 0) { ad[r] = 0.f; mk[r] = 1.f; continue; }
+#endif
+          const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
+          ad[r] = buf_load1s(radd, va, row * lda4);
+          mk[r] = 1.f;
+          if (BMODE == 1) mk[r] = buf_load1s(rmask, vm, row * ldm4);      // null mask: empty descriptor, reads 0 (selected away below)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2));
+          float v = acc[i][j][r] * sc + sh + ad[r];
+          if (BMODE == 1) v = (has_mask & !(mk[r] > 0.f)) ? 0.f : v;
+          if (SIG) {
+            const float sg = 1.f / (1.f + __expf(-v));
+            v = n < g.act_cols ? sg : v;
+          } else {
+            const float vr = fmaxf(v, 0.f);
+            v = relu ? vr : v;
+          }
+#ifdef RADNET_DIAG_SKIP_EPILOGUE
+          if (r != 0) { asm volatile("" ::"v"(v)); continue; }
+#endif
+          if (COH) buf_store1_sc1(ry, vy + row * ldy4, v);
+          else buf_store1(ry, vy + row * ldy4, v);      // one add; a STORE with a non-zero SGPR offset is slow (see above)
+        }
+      }
+    }
+  };
+  if (g.act == 2) out_tiles(std::true_type{});
+  else out_tiles(std::false_type{});
 #ifdef RADNET_DIAG_STAMPS
   write_stamps();
 #endif
+}
+
+template <int BM, int BN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) conv_igemm_persist_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<BM, BN, 0>() + igemm_persist_scratch_floats<BM, BN, WAVES>()];
+  if (g.xcd_batch) {                    // see conv_igemm_kernel
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), per = total >> 3;
+    const unsigned l2 = lin < (per << 3) ? (lin & 7u) * per + (lin >> 3) : lin;
+    const unsigned z = l2 / (gx * gy), r = l2 - z * gx * gy, y = r / gx;
+    conv_igemm_body<BM, BN, 0, false, WAVES, false, true>(g, lds, r - y * gx, y, z, gx);
+    return;
+  }
+  conv_igemm_body<BM, BN, 0, false, WAVES, false, true>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 template <int BM, int BN, int BMODE, bool SMALLC, int WAVES>
@@ -1047,21 +1184,44 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& g, float* __res
     }
   }
 
+  if (!ordered && g.atomic) {                    // RADNET_DETERMINISTIC=0: the splits add with fp32 atomics
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = k0 + wm * (BMK / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (n < g.N && k < g.K) atomicAdd(g.dw + bp * g.dw_bstride + (size_t)k * g.ldw + n, acc[i][j][r]);
+        }
+      }
+    }
+    return;
+  }
+  // Plain stores / ordered accumulate, straight-line (round 4; the first form decided ordered / accumulate / atomic and the two
+  // bounds per accumulator register -- five branches each, and in accumulate mode a load + wait + store round trip per register):
+  // rows past K and columns past N fall outside the descriptor, accumulate mode reads a tile's 16 old values in one round trip.
+  const __amdgpu_buffer_rsrc_t rdw = make_rsrc(g.dw + bp * g.dw_bstride, (unsigned)((size_t)g.K * (size_t)g.ldw * 4u));
+  const bool rmw = ordered && g.accumulate;
+  const unsigned ldw4 = (unsigned)g.ldw * 4u;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int kb = k0 + wm * (BMK / 2) + i * 32 + 4 * hi;
+      const unsigned voff = (n < g.N && kb < g.K) ? ((unsigned)kb * (unsigned)g.ldw + (unsigned)n) * 4u : kOOB;
+      float old[16];
+      if (rmw) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wm * (BMK / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (n < g.N && k < g.K) {
-          float* p = g.dw + bp * g.dw_bstride + (size_t)k * g.ldw + n;
-          if (ordered) *p = g.accumulate ? *p + acc[i][j][r] : acc[i][j][r];
-          else if (g.atomic) atomicAdd(p, acc[i][j][r]);
-          else *p = acc[i][j][r];
-        }
+        for (int r = 0; r < 16; ++r) old[r] = buf_load1(rdw, voff + (unsigned)((r & 3) + 8 * (r >> 2)) * ldw4);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf_store1(rdw, voff + (unsigned)((r & 3) + 8 * (r >> 2)) * ldw4, rmw ? old[r] + acc[i][j][r] : acc[i][j][r]);
     }
   }
 }
@@ -1243,10 +1403,26 @@ template <int BMODE, bool SMALLC, int WAVES>
 void launch_igemm_w(hipStream_t st, const GemmArgs& g, const TileChoice& tc, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
   dim3 block(64 * WAVES);
   // (capping workgroups per CU with extra dynamic LDS was measured: 7-25 % slower on every layer -- co-residency wins)
+  if constexpr (WAVES == 4 && !SMALLC) {        // the 32-row tiles exist in the 4-wave form only (8 waves: fewer than one A chunk per thread)
+    if (tc.bm == 32 && tc.bn == 64) { RADNET_LAUNCH((conv_igemm_kernel<32, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g); return; }
+    if (tc.bm == 32 && tc.bn == 32) { RADNET_LAUNCH((conv_igemm_kernel<32, 32, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g); return; }
+  }
   if (tc.bm == 128 && tc.bn == 128) RADNET_LAUNCH((conv_igemm_kernel<128, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
   else if (tc.bm == 128 && tc.bn == 64) RADNET_LAUNCH((conv_igemm_kernel<128, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
   else if (tc.bm == 64 && tc.bn == 128) RADNET_LAUNCH((conv_igemm_kernel<64, 128, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
   else RADNET_LAUNCH((conv_igemm_kernel<64, 64, BMODE, SMALLC, WAVES>), grid, block, 0, st, e0, e1, g);
+}
+
+// persistent batched launch: the tile shapes that have the PERSIST form (forward, channel-tiled, 4 waves)
+inline bool persist_shape(const TileChoice& tc) {
+  return tc.waves != 8 && ((tc.bm == 64 && tc.bn == 64) || (tc.bm == 32 && tc.bn == 64) || (tc.bm == 64 && tc.bn == 128) || (tc.bm == 32 && tc.bn == 32));
+}
+void launch_igemm_persist(hipStream_t st, const GemmArgs& g, const TileChoice& tc, hipEvent_t e0, hipEvent_t e1) {
+  dim3 grid(radnet_cdiv(g.M, tc.bm), radnet_cdiv(g.N, tc.bn), radnet_cdiv(g.batch, g.zper)), block(256);
+  if (tc.bm == 64 && tc.bn == 64) RADNET_LAUNCH((conv_igemm_persist_kernel<64, 64, 4>), grid, block, 0, st, e0, e1, g);
+  else if (tc.bm == 32 && tc.bn == 64) RADNET_LAUNCH((conv_igemm_persist_kernel<32, 64, 4>), grid, block, 0, st, e0, e1, g);
+  else if (tc.bm == 64 && tc.bn == 128) RADNET_LAUNCH((conv_igemm_persist_kernel<64, 128, 4>), grid, block, 0, st, e0, e1, g);
+  else RADNET_LAUNCH((conv_igemm_persist_kernel<32, 32, 4>), grid, block, 0, st, e0, e1, g);
 }
 
 template <int BMODE, bool SMALLC>
@@ -1312,8 +1488,21 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     g.units = nullptr;
     g.partial = nullptr;
     g.counters = nullptr;
-    if (g.batch > 1 && t.splits != 1 && t.splits != -1) return RADNET_ERR_UNSUPPORTED;      // a batch is its own source of workgroups
-    g.xcd_batch = (g.batch > 1 && t.splits == -1) ? 1 : 0;        // -1: the same plain grid, XCD-contiguous numbering
+    // a batch is its own source of workgroups: no K slices.  |slices| = z > 1 on a batch = the persistent form, z consecutive problems
+    // per workgroup (plain epilogue, dense problem strides, forward only, the tile shapes of persist_shape)
+    g.zper = 0;
+    if (g.batch > 1 && t.splits != 1 && t.splits != -1) {
+      const int z = t.splits < 0 ? -t.splits : t.splits;
+      const bool plain = !g.scale && !g.shift && !g.addend && !g.mask && !g.in_scale && g.act == 0 && g.npos == 1 && g.stride == 1;
+      if (bmode != 0 || smallc || !plain || !persist_shape(t) || z > 12 || z > g.batch || g.x_bstride != (long long)g.M * g.C ||
+          g.w_bstride != (long long)g.K * g.ldw || (uint64_t)z * (uint64_t)std::max(g.x_bstride, g.w_bstride) * 4ull >= (1ull << 31))
+        return RADNET_ERR_UNSUPPORTED;
+      g.zper = z;
+    }
+    if (t.bm < 64 || t.bn < 64) {               // 32-row tiles: 4 waves, channel-tiled layers, 32x64 and 32x32 only
+      if (t.waves == 8 || smallc || t.bm != 32 || (t.bn != 64 && t.bn != 32)) return RADNET_ERR_UNSUPPORTED;
+    }
+    g.xcd_batch = (g.batch > 1 && t.splits < 0) ? 1 : 0;          // negative: the same grid, XCD-contiguous numbering
     if (g.batch <= 1 && (t.splits > 1 || t.splits < 0)) {
       tb = get_unit_table(ctx, g.M, g.N, g.K, t.bm, t.bn, t.splits);
       if (!tb) RADNET_FAIL(ctx, RADNET_ERR_HIP, "conv: cannot build the work-unit table");
@@ -1338,7 +1527,9 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
       pc->flops += 2.0 * g.M * g.N * g.K;
       return RADNET_OK;
     }
-    if (bmode == 0) {
+    if (g.zper > 1) {
+      launch_igemm_persist(ctx->stream, g, t, ctx->arm0, ctx->arm1);
+    } else if (bmode == 0) {
       if (smallc) launch_igemm<0, true>(ctx->stream, g, t, n_units, ctx->arm0, ctx->arm1);
       else launch_igemm<0, false>(ctx->stream, g, t, n_units, ctx->arm0, ctx->arm1);
     } else {
@@ -1353,7 +1544,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
   auto it = ctx->tuned->find(key);
   if (ctx->force_a > 0) {                      // radnet_force_config: tests sweep every tile / slice / order variant
     tc = TileChoice{ctx->force_a, ctx->force_b, ctx->force_splits, ctx->force_waves == 8 ? 8 : 4};
-    if (tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
+    if (g.batch <= 1 && tc.splits > 1 && nk / tc.splits < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: forced %d K slices but only %d K tiles", tc.splits, nk);
   } else if (it != ctx->tuned->end()) {
     tc = TileChoice{it->second.a, it->second.b, it->second.splits, it->second.waves == 8 ? 8 : 4};
   } else if (const radnet_tuned* nb = ctx->autotune == 2 ? radnet_tuned_neighbour(*ctx->tuned, key) : nullptr) {
@@ -1361,7 +1552,10 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     (*ctx->tuned)[key] = *nb;
   } else if (ctx->autotune) {
     PairPause pause(ctx);                       // trial launches are real launches
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    // 32-row tiles (round 4): M = 980 / 2 394 / 160 rows fill 256 CUs without K slices (no slab seam, no last-arriver tail) and
+    // waste no rows where M is a multiple of 32 but not of 64; tried only where the 64x64 grid is small (they re-read B twice as often)
+    const int cand[6][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
+    const long long tiles64 = (long long)radnet_cdiv(g.M, 64) * radnet_cdiv(g.N, 64) * (g.batch > 1 ? g.batch : 1);
     const int chunks[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};      // K slices per tile
     std::vector<std::pair<float, TileChoice>> seen;
     // A data gradient measured on behalf of radnet_conv_bwd is tuned WITHIN the shapes its one-launch form takes (64x64 tiles,
@@ -1369,15 +1563,16 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     // launch beat "fastest dgrad + wgrad, one after the other" for every classifier layer measured in situ (tools/insitu_tune.py:
     // +2.7 % and +1.3 % on the whole step for the two layers the isolated choice had unpaired)
     const bool for_pair = pause.saved != nullptr && bmode == 1 && !smallc && g.batch <= 1;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 6; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
       if (for_pair && (cand[c][0] != 64 || cand[c][1] != 64)) continue;
+      if (cand[c][0] < 64 && (smallc || tiles64 > 6 * kNumCU)) continue;
       const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
       for (int s : chunks) {
-        if (s > 1 && (ctx->ws == nullptr || nk / s < 2)) continue;               // slices shorter than 2 k-tiles
+        if (g.batch > 1 ? (s > 12 || s > g.batch) : (s > 1 && (ctx->ws == nullptr || nk / s < 2))) continue;      // slices shorter than 2 k-tiles (a batch: s = problems per workgroup)
         for (int sign = 1; sign >= -1; sign -= 2) {                             // -s = same slices, XCD-aware unit order
           if (sign < 0 && tiles * s * (g.batch > 1 ? g.batch : 1) < 16) continue;
-          for (int waves = 4; waves <= (for_pair ? 4 : 8); waves += 4) {        // 8 = K tile halved between two wave grids
+          for (int waves = 4; waves <= ((for_pair || cand[c][0] < 64) ? 4 : 8); waves += 4) {        // 8 = K tile halved between two wave grids
             TileChoice t{cand[c][0], cand[c][1], sign * s, waves};
             float ms = 0.f;
             int rc = radnet_time_launches(ctx, [&]() { return launch(t); }, 3, &ms);
@@ -1443,10 +1638,14 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
 //     with agent-scope loads.  Consumers read the data with ordinary loads: a line of an activation tensor is complete before
 //     any workgroup may touch it (the counters cover whole rows of whole tiles, tensors are not shared, a launch starts with
 //     clean caches), so no cache on the reader's side can hold an older copy;
-//   * items are drawn with one atomic per workgroup in list order and the list is topologically sorted, so the lowest
-//     unfinished item is always held by a running workgroup whose inputs are finished or running: no deadlock for any grid
-//     size; a poll that does not see its counters move within ~2 s raises `error` and every workgroup leaves (the grid
-//     always drains);
+//   * items are DEALT statically (workgroup b runs items b, b + grid, b + 2 grid, ...: a shared queue head cost one same-address
+//     atomic per item) and the list is topologically sorted, so the lowest unfinished item belongs to a workgroup whose earlier
+//     items are finished -- i.e. it is being run -- PROVIDED EVERY WORKGROUP OF THE GRID IS RESIDENT: the deal is deadlock-free
+//     only while grid (x the number of chains running at the same time, plus whatever other launches hold CU slots) fits the
+//     chip's 4 workgroups per CU.  radnet_chain_build caps one grid at 4 * 256; the engine divides that by the chains it runs
+//     side by side.  A poll that does not see its counters move within 1 s raises `error` and every workgroup leaves (the grid
+//     always drains); the launch's outputs are then INVALID and radnet_chain_run of the NEXT launch of that chain returns
+//     RADNET_ERR_HIP (the sticky hdr->last_error travels to a mapped host word), as does radnet_chain_status;
 //   * the last workgroup to leave zeroes the counters and the queue head: the launch can be replayed (hipGraph).
 // A narrow grid (1-2 workgroups per CU) leaves CU slots to the other lanes' launches: the frozen base forward of an announced
 // batch is background work in the pipelined step.
@@ -1467,7 +1666,7 @@ struct ChainItem {
 };
 struct ChainHeader {
   unsigned next, exited, error, last_error;
-  unsigned runs, pad[3];
+  unsigned runs, host_lo, host_hi, pad;       // host_lo/hi: a mapped host word that receives the first error (radnet_chain_error: no sync)
 };
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -1665,7 +1864,11 @@ __device__ __forceinline__ void chain_body(ChainHeader* __restrict__ hdr, const 
       for (unsigned i = tid; i < n_counters; i += NTHREADS) __hip_atomic_store(counters + (size_t)i * kCtrStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
       const unsigned e = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0u && hdr->last_error == 0u) hdr->last_error = e;
+      if (e != 0u && hdr->last_error == 0u) {
+        hdr->last_error = e;
+        unsigned* hp = reinterpret_cast<unsigned*>(((unsigned long long)hdr->host_hi << 32) | (unsigned long long)hdr->host_lo);
+        if (hp != nullptr) __hip_atomic_store(hp, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       hdr->runs += 1u;
       __hip_atomic_store(&hdr->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&hdr->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1775,6 +1978,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
     g.dy_bytes = (unsigned)db;
   }
   if (d->c % 64) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: channels %d not a multiple of 64", d->c);
+  if ((uint64_t)g.K * (uint64_t)g.ldw * 4ull >= (1ull << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv_wgrad: weight tensor larger than 2 GiB");
   const int nmt = radnet_cdiv(g.M, BK);
   uint64_t wgrad_slab_bytes = 0;
   auto launch = [&](int bmk, int bn, int splits) -> int {
@@ -1828,6 +2032,7 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   auto it = ctx->tuned->find(key);
   if (ctx->force_a > 0) {
     bmk = ctx->force_a; bn = ctx->force_b; splits = ctx->force_splits < 1 ? 1 : ctx->force_splits;
+    if (bmk < 64 || bn < 64) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced tile %dx%d (the weight-gradient kernel has 64 / 128 tiles)", bmk, bn);
     if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced k tile %d does not divide c=%d", bmk, d->c);
   } else if (it != ctx->tuned->end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
@@ -1971,6 +2176,7 @@ struct radnet_chain {
   int* d_units = nullptr;
   float* d_slabs = nullptr;
   unsigned* d_marks = nullptr;      // RADNET_CHAIN_DEBUG=1: one word per wave (phase, item)
+  unsigned* h_err = nullptr;        // mapped host word: first 'gave up waiting' error of any launch (1 + item), sticky
   unsigned n_items = 0, n_counters = 0, n_stages = 0;
   int grid = 0;
   std::vector<ChainItem> h_items;       // host copies for radnet_chain_peek / diagnosis
@@ -2024,6 +2230,7 @@ extern "C" void radnet_chain_destroy(radnet_chain* ch) {
   if (!ch) return;
   for (void* p : {(void*)ch->d_hdr, (void*)ch->d_stages, (void*)ch->d_items, (void*)ch->d_counters, (void*)ch->d_need, (void*)ch->d_units, (void*)ch->d_slabs, (void*)ch->d_marks})
     if (p) (void)hipFree(p);
+  if (ch->h_err) (void)hipHostFree(ch->h_err);
   delete ch;
 }
 
@@ -2149,6 +2356,16 @@ static int chain_plan(const radnet_op* ops, int32_t n_ops, ChainPlan& pl, ErrSin
     return RADNET_OK;
   };
 
+  // Every tensor is written ONCE per launch and never after it has been read (consumers use ordinary loads: a cache line is complete
+  // before any workgroup touches it; the counters order a reader behind its producer -- RAW -- and nothing else).  A list that
+  // re-uses a buffer (ping-pong activations, an output written twice, an output that an earlier op read) has WAR / WAW hazards the
+  // counters do not cover: refused here, the caller keeps the launch list.
+  std::set<const void*> touched;
+  auto claim_output = [&](const void* p, int k, const char* what) -> int {
+    if (p != nullptr && touched.count(p)) RADNET_FAIL(&ec, RADNET_ERR_UNSUPPORTED, "chain: op %d writes %s that an earlier op of the list reads or writes (buffer re-use inside a chain)", k, what);
+    touched.insert(p);
+    return RADNET_OK;
+  };
   for (int k = 0; k < n_ops; ++k) {
     const radnet_op& op = ops[k];
     if (op.kind == RADNET_OP_NOP) continue;
@@ -2156,6 +2373,10 @@ static int chain_plan(const radnet_op* ops, int32_t n_ops, ChainPlan& pl, ErrSin
       ChainStage st{};
       st.type = 0;
       int rc = chain_conv_args(&ec, &op.conv, st.g);
+      if (rc != RADNET_OK) return rc;
+      touched.insert(op.conv.x);
+      if (op.conv.addend) touched.insert(op.conv.addend);
+      rc = claim_output(op.conv.y, k, "its output");
       if (rc != RADNET_OK) return rc;
       const int si = push_stage(st, ChainOut{});
       auto pm = producer.find(op.conv.x), pa = op.conv.addend ? producer.find(op.conv.addend) : producer.end();
@@ -2169,6 +2390,11 @@ static int chain_plan(const radnet_op* ops, int32_t n_ops, ChainPlan& pl, ErrSin
       float* V = (float*)op.p[1];
       const float* U = (const float*)op.p[2];
       float* Mw = (float*)op.p[3];
+      touched.insert(x);
+      for (int q : {1, 3, 6}) {
+        const int rcq = claim_output(op.p[q], k, q == 1 ? "its transformed input" : q == 3 ? "its product buffer" : "its output");
+        if (rcq != RADNET_OK) return rcq;
+      }
       const int nb = op.i[0], h = op.i[1], w = op.i[2], c = op.i[3], n = op.i[4], T = op.i[5], act = op.i[6], ldy = op.i[7];
       const int th = (h + 3) / 4, tw = (w + 3) / 4;
       if (T != nb * th * tw || (c & 63) || (n & 63) || !(256 % c == 0 || c % 256 == 0) || !(256 % n == 0 || n % 256 == 0))
@@ -2343,6 +2569,14 @@ extern "C" int radnet_chain_build(radnet_ctx* ctx, const radnet_op* ops, int32_t
     return RADNET_ERR_HIP;
   };
   if (hipMalloc((void**)&ch->d_hdr, sizeof(ChainHeader)) != hipSuccess || hipMemset(ch->d_hdr, 0, sizeof(ChainHeader)) != hipSuccess) return fail("header");
+  {
+    if (hipHostMalloc((void**)&ch->h_err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return fail("error word");
+    *ch->h_err = 0u;
+    ChainHeader h0{};
+    h0.host_lo = (unsigned)((unsigned long long)(uintptr_t)ch->h_err & 0xffffffffull);
+    h0.host_hi = (unsigned)((unsigned long long)(uintptr_t)ch->h_err >> 32);
+    if (hipMemcpy(ch->d_hdr, &h0, sizeof(h0), hipMemcpyHostToDevice) != hipSuccess) return fail("header");
+  }
   if (hipMalloc((void**)&ch->d_counters, need.size() * 4 * kCtrStride) != hipSuccess || hipMemset(ch->d_counters, 0, need.size() * 4 * kCtrStride) != hipSuccess) return fail("counters");
   if (hipMalloc((void**)&ch->d_need, need.size() * 4) != hipSuccess || hipMemcpy(ch->d_need, need.data(), need.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("need");
   if (!units.empty() && (hipMalloc((void**)&ch->d_units, units.size() * 4) != hipSuccess || hipMemcpy(ch->d_units, units.data(), units.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) return fail("units");
@@ -2400,8 +2634,13 @@ extern "C" int radnet_chain_peek(radnet_chain* ch, int32_t item, uint32_t* out, 
   return ok ? pairs : RADNET_ERR_HIP;
 }
 
+extern "C" uint32_t radnet_chain_error(radnet_chain* ch) { return (ch && ch->h_err) ? *(volatile unsigned*)ch->h_err : 0u; }
+
 extern "C" int radnet_chain_run(radnet_ctx* ctx, radnet_chain* ch) {
   if (!ctx || !ch) return RADNET_ERR_ARG;
+  if (const uint32_t e = radnet_chain_error(ch))
+    RADNET_FAIL(ctx, RADNET_ERR_HIP, "chain: an earlier launch of this chain gave up waiting at item %u (not every workgroup of its grid was resident?): "
+                "its outputs were invalid", e - 1u);
   radnet_timing_arm(ctx);
   static const int variant = getenv("RADNET_CHAIN_VARIANT") ? atoi(getenv("RADNET_CHAIN_VARIANT")) : 0;      // diagnosis
   if (variant == 1)

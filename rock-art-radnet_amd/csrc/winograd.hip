@@ -422,6 +422,105 @@ __global__ void __launch_bounds__(256) wino4_filter_grad_kernel(const float* __r
   }
 }
 
+// ---- round 4: the two per-layer transforms with SIX threads per (tile, 4 channels) ---------------------------------------------
+// The one-thread-per-unit kernels above give a 160-tile stage-4 layer 40 workgroups, each thread walking 36 loads and 36 stores
+// on its own.  Here a unit's six patch columns (input) / six position columns (output) go to six WAVES of a 384-thread workgroup
+// (role = wave, unit = lane: every access of a wave is 64 consecutive channel quads = 1 KB): role r transforms column r along the
+// rows (6 loads), the 6x6 (6x4) intermediate crosses through LDS, role r then transforms ROW r along the columns and stores it --
+// 6 + 6 memory operations per thread, 4 times the workgroups.  Same operations in the same order as the kernels above: same bits.
+__global__ void __launch_bounds__(384) wino4_input_v2_kernel(const float* __restrict__ x, int nb, int H, int W_, int C, int TH, int TW,
+                                                             float* __restrict__ V) {
+  __shared__ float4 lds[36 * 64];
+  const int cv = C >> 2;
+  const unsigned T = (unsigned)(nb * TH * TW), total = T * (unsigned)cv;
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const unsigned i = blockIdx.x * 64u + (unsigned)lane;
+  const bool live = i < total;
+  const unsigned ii = live ? i : 0u;
+  const unsigned tile = ii / (unsigned)cv;
+  const int cq = (int)(ii - tile * (unsigned)cv);
+  const unsigned trow = tile / (unsigned)TW;
+  const int tj = (int)(tile - trow * (unsigned)TW);
+  const int img = (int)(trow / (unsigned)TH);
+  const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
+  {
+    const int iw = 4 * tj - 1 + role;
+    float4 col[6], o[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int ih = 4 * ti - 1 + a;
+      col[a] = (live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W_)
+                   ? *reinterpret_cast<const float4*>(x + (((long long)img * H + ih) * W_ + iw) * C + cq * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bt6(col, o);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) lds[(a * 6 + role) * 64 + lane] = o[a];
+  }
+  __syncthreads();
+  {
+    float4 row[6], o[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) row[b] = lds[(role * 6 + b) * 64 + lane];
+    bt6(row, o);
+    if (live) {
+      float4* dst = reinterpret_cast<float4*>(V) + (size_t)tile * cv + cq;
+      const size_t ps = total;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) dst[(size_t)(6 * role + b) * ps] = o[b];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(384) wino4_output_v2_kernel(const float* __restrict__ Mm, int nb, int OH, int OW, int N, int TH, int TW,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                              float* __restrict__ y, int ldy) {
+  __shared__ float4 lds[24 * 64];
+  const int nv = N >> 2;
+  const unsigned T = (unsigned)(nb * TH * TW), total = T * (unsigned)nv;
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const unsigned i = blockIdx.x * 64u + (unsigned)lane;
+  const bool live = i < total;
+  const unsigned ii = live ? i : 0u;
+  const unsigned tile = ii / (unsigned)nv;
+  const int nq = (int)(ii - tile * (unsigned)nv);
+  {
+    const float4* src = reinterpret_cast<const float4*>(Mm) + (size_t)tile * nv + nq;
+    const size_t ps = total;
+    float4 col[6], o[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) col[a] = live ? src[(size_t)(6 * a + role) * ps] : make_float4(0.f, 0.f, 0.f, 0.f);
+    at6(col, o);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) lds[(a * 6 + role) * 64 + lane] = o[a];
+  }
+  __syncthreads();
+  if (role < 4 && live) {
+    const unsigned trow = tile / (unsigned)TW;
+    const int tj = (int)(tile - trow * (unsigned)TW);
+    const int img = (int)(trow / (unsigned)TH);
+    const int ti = (int)(trow - (unsigned)img * (unsigned)TH);
+    float4 row[6], o[4];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) row[b] = lds[(role * 6 + b) * 64 + lane];
+    at6(row, o);
+    const int oh = 4 * ti + role;
+    if (oh < OH) {
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (scale) sc = *reinterpret_cast<const float4*>(scale + nq * 4);
+      if (shift) sh = *reinterpret_cast<const float4*>(shift + nq * 4);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ow = 4 * tj + b;
+        if (ow >= OW) continue;
+        float4 v = scale ? o[b] * sc + sh : o[b] + sh;
+        if (act == 1) v = vmax0(v);
+        *reinterpret_cast<float4*>(y + (((long long)img * OH + oh) * OW + ow) * ldy + nq * 4) = v;
+      }
+    }
+  }
+}
+
 // One thread per (tile | filter element, 4 channels).  Narrower per-thread vectors (float2 / float: 2x / 4x the workgroups for
 // the 160-tile stage-4 layers) were measured and changed nothing -- input transform 6.3 us, output 5.9 us either way: at a few
 // MB per launch these kernels last one launch + one memory round trip, not a bandwidth- or occupancy-limited time.
@@ -503,7 +602,10 @@ extern "C" int radnet_winograd4_input(radnet_ctx* ctx, const float* x, int32_t n
   if (c & 3) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_input: c=%d must be a multiple of 4", c);
   const int th = (h + 3) / 4, tw = (w + 3) / 4;
   if ((long long)nb * th * tw * (c / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_input_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (c / 4)));
-  RADNET_WINO4_LAUNCH(wino4_input_kernel, (long long)nb * th * tw * (c / 4), x, nb, h, w, c, th, tw, v);
+  static const bool v1 = getenv("RADNET_WINO_V1") != nullptr;      // A/B: the one-thread-per-unit kernels
+  const long long units = (long long)nb * th * tw * (c / 4);
+  if (v1) RADNET_WINO4_LAUNCH(wino4_input_kernel, units, x, nb, h, w, c, th, tw, v);
+  else hipLaunchKernelGGL(wino4_input_v2_kernel, dim3((unsigned)((units + 63) / 64)), dim3(384), 0, ctx->stream, x, nb, h, w, c, th, tw, v);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_input");
   return RADNET_OK;
 }
@@ -514,7 +616,10 @@ extern "C" int radnet_winograd4_output(radnet_ctx* ctx, const float* m, int32_t 
   if ((n & 3) || (ldy & 3) || ldy < n) RADNET_FAIL(ctx, RADNET_ERR_ARG, "winograd4_output: n=%d, ldy=%d", n, ldy);
   const int th = (oh + 3) / 4, tw = (ow + 3) / 4;
   if ((long long)nb * th * tw * (n / 4) >= (1ll << 31)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "wino4_output_kernel: %lld work items (32-bit index arithmetic)", (long long)((long long)nb * th * tw * (n / 4)));
-  RADNET_WINO4_LAUNCH(wino4_output_kernel, (long long)nb * th * tw * (n / 4), m, nb, oh, ow, n, th, tw, scale, shift, act, y, ldy);
+  static const bool v1 = getenv("RADNET_WINO_V1") != nullptr;
+  const long long units = (long long)nb * th * tw * (n / 4);
+  if (v1) RADNET_WINO4_LAUNCH(wino4_output_kernel, units, m, nb, oh, ow, n, th, tw, scale, shift, act, y, ldy);
+  else hipLaunchKernelGGL(wino4_output_v2_kernel, dim3((unsigned)((units + 63) / 64)), dim3(384), 0, ctx->stream, m, nb, oh, ow, n, th, tw, scale, shift, act, y, ldy);
   RADNET_CHECK_LAUNCH(ctx, "winograd4_output");
   return RADNET_OK;
 }

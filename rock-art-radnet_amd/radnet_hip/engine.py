@@ -163,6 +163,7 @@ class FasterRCNNEngine:
         # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
         # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
+        self._chain_plans = []     # plans whose base forward is a chain launch: check_chains() reads their sticky error words
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
@@ -512,7 +513,18 @@ class FasterRCNNEngine:
         sub = plan["ops"][first:]
         arr = self._compile(sub)
         h = C.c_void_p()
-        rc = self.lib.radnet_chain_build(self.ctx.h, C.cast(arr, C.c_void_p), len(sub), self.chain_wgs, C.byref(h))
+        # the static deal needs every workgroup of every chain that runs at the same time resident (4 per CU = 1 024 slots): one
+        # chain per prefetch lane may be in flight, and the RPN / classifier lanes' launches need room beside them
+        lanes = max(1, getattr(self, "n_side_lanes", 1))
+        cap = max(64, (4 * 256) // (lanes + 1))
+        wgs = self.chain_wgs if self.chain_wgs > 0 else 512
+        if wgs > cap:
+            if not getattr(self, "_chain_clamped", False):
+                self._chain_clamped = True
+                import sys
+                sys.stderr.write("radnet: RADNET_CHAIN_WGS=%d exceeds what %d concurrent chains can keep resident; using %d\n" % (wgs, lanes, cap))
+            wgs = cap
+        rc = self.lib.radnet_chain_build(self.ctx.h, C.cast(arr, C.c_void_p), len(sub), wgs, C.byref(h))
         if rc != 0:
             if not getattr(self, "_chain_warned", False):
                 self._chain_warned = True
@@ -522,6 +534,20 @@ class FasterRCNNEngine:
         plan["chain"] = h
         plan["chain_sub"] = sub                           # keeps the descriptors (and the compiled array) alive
         plan["ops"] = plan["ops"][:first] + [("chain", h)]
+        self._chain_plans.append(plan)
+
+    def check_chains(self):
+        """Raise if any chain launch so far gave up waiting (its feature map was invalid).  Reads the chains' mapped host error
+        words: no synchronisation -- called where the host has just waited for something downstream of the base forward
+        (roi_targets_finish, TrainStep.flush / validate, base_forward of a plan that runs again)."""
+        for plan in self._chain_plans:
+            h = plan.get("chain")
+            if h is not None:
+                e = int(self.lib.radnet_chain_error(h))
+                if e:
+                    raise L.RadnetError("chain launch gave up waiting at work item %d: not every workgroup of its grid was resident "
+                                        "(RADNET_CHAIN_WGS too large for the launches running beside it?); the feature maps it "
+                                        "produced are invalid" % (e - 1))
 
     def chain_status(self, plan):
         """(last_error, runs, items, stages, executed flops, algorithmic flops) of a plan's chain; synchronises the lane."""
@@ -537,6 +563,7 @@ class FasterRCNNEngine:
         if plan.get("chain") is not None:
             self.lib.radnet_chain_destroy(plan["chain"])
             plan["chain"] = None
+            self._chain_plans = [p for p in self._chain_plans if p is not plan]
         lists = set()
         for v in plan.values():
             if isinstance(v, list):
@@ -1228,10 +1255,11 @@ class FasterRCNNEngine:
         P["event"].record()
         return P
 
-    @staticmethod
-    def roi_targets_finish(P):
+    def roi_targets_finish(self, P):
         """Waits for the class codes only (an event after their copy), not for whatever was enqueued behind them."""
         P["event"].synchronize()
+        if self._chain_plans:
+            self.check_chains()            # the codes depend on the base forward: a chain that gave up has written its error word by now
         n = int(P["h_n"][0])
         return P, P["h_cls"].numpy()[:max(n, 0)], n
 

@@ -86,11 +86,12 @@ def neighbours(key, cur):
             out.append((a, b, -s, w))                      # the other workgroup order (plain / XCD-contiguous)
     elif abs(s) == 1:
         out.append((a, b, -s, w))                          # batched launch: plain / XCD-contiguous numbering of its workgroups
-    out.append((a, b, s, 12 - w))                          # 4 <-> 8 waves
-    for ta in (64, 128):
-        for tb in (64, 128):
-            if (ta, tb) != (a, b) and not (tb > 64 and n <= 64) and not (ta > 64 and m <= 64):
-                out.append((ta, tb, s if batched else (1 if abs(s) == 1 else s), w))
+    if a >= 64:
+        out.append((a, b, s, 12 - w))                      # 4 <-> 8 waves (the 32-row tiles exist with 4 waves only)
+    small = npos * c == k and c % BK == 0 and cdiv(m, 64) * cdiv(n, 64) * (stride if batched else 1) <= 6 * 256
+    for ta, tb in ((64, 64), (64, 128), (128, 64), (128, 128), (32, 64), (32, 32)):
+        if (ta, tb) != (a, b) and not (tb > 64 and n <= 64) and not (ta > 64 and m <= 64) and (ta >= 64 or small):
+            out.append((ta, tb, s if batched else (1 if abs(s) == 1 else s), 4 if ta < 64 else w))
     seen, uniq = set(), []
     for o in out:
         if o not in seen and o != (a, b, s, w):

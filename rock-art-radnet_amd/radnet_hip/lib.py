@@ -209,6 +209,7 @@ def load_library():
         "radnet_comm_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "radnet_chain_build": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "radnet_chain_run": (C.c_int, [vp, vp]),
+        "radnet_chain_error": (C.c_uint32, [vp]),
         "radnet_chain_status": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
         "radnet_chain_destroy": (None, [vp]),
         "radnet_chain_peek": (C.c_int, [vp, i32, C.POINTER(C.c_uint32), i32]),

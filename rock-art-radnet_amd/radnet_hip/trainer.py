@@ -132,6 +132,8 @@ class TrainStep:
             self._head_last = None
         self._lane_mode = False
         self._finish_head_update()
+        if getattr(self.eng, "_chain_plans", None):
+            self.eng.check_chains()
 
     VAL_SLOT = 97          # buffer set of the validation pass (plans are keyed by slot: never one of the training step's)
 

@@ -34,6 +34,8 @@ FWD_SHAPES = [
     (1, 17, 19, 224, 64, 1, 1, 0),           # 7 K tiles (odd): exercises the two-stage pipeline tail
 ]
 CONFIGS = [(bm, bn, s, wv) for bm, bn in itertools.product((64, 128), (64, 128)) for s in (1, 2, 3, 5, -1, -4) for wv in (4, 8)]
+# round 4: 32-row tiles (one wave row, the K tile split between the waves left over), 4 waves only
+CONFIGS += [(32, bn, s, 4) for bn in (64, 32) for s in (1, 2, 3, 5, -1, -4)]
 
 
 @pytest.mark.parametrize("shape", FWD_SHAPES)
@@ -114,7 +116,7 @@ def test_batched_launches_xcd_contiguous_numbering_changes_no_bit(ctx, shape):
     U = dev(rs.standard_normal((batch, c, n)).astype(np.float32))
     dZ = dev(rs.standard_normal((batch, T, n)).astype(np.float32))
     ref = np.einsum("ptc,pcn->ptn", V.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
-    for bm, bn, wv in [(64, 64, 4), (64, 64, 8), (64, 128, 4), (128, 64, 4), (128, 128, 8)]:
+    for bm, bn, wv in [(64, 64, 4), (64, 64, 8), (64, 128, 4), (128, 64, 4), (128, 128, 8), (32, 64, 4), (32, 32, 4)]:
         if bn > 64 and n <= 64:
             continue
         out = {}
@@ -126,6 +128,16 @@ def test_batched_launches_xcd_contiguous_numbering_changes_no_bit(ctx, shape):
             out[s] = M.cpu().numpy()
         assert np.array_equal(out[1], out[-1]), (shape, bm, bn, wv)
         close(out[-1], ref)
+        # round 4, persistent form (|slices| = z > 1 on a batch): z consecutive problems per workgroup as one long K loop --
+        # the same sums in the same order, so the same bits; z that does not divide the batch leaves a shorter last group
+        if wv == 4 and (bm, bn) in ((64, 64), (32, 64), (64, 128), (32, 32)):
+            for z in (2, 3, -4, 5, 7, -12):
+                if abs(z) > batch:
+                    continue
+                ctx.check(ctx.lib.radnet_force_config(ctx.h, bm, bn, z), "force")
+                M = torch.full((batch, T, n), float("nan"), device="cuda")
+                ctx.call("radnet_gemm_batched", V, U, M, batch, T, n, c)
+                assert np.array_equal(M.cpu().numpy(), out[1]), (shape, bm, bn, z)
     ctx.check(ctx.lib.radnet_force_waves(ctx.h, 0), "waves off")
     dref = np.einsum("ptc,ptn->pcn", V.cpu().numpy().astype(np.float64), dZ.cpu().numpy().astype(np.float64))
     for bmk, bn in [(64, 64), (64, 128), (128, 64) if c % 128 == 0 else (64, 64)]:
