@@ -49,7 +49,7 @@ def make_batch(rank, per_gpu, H, W):
     return batch
 
 
-def cpu_baseline(budget_s=25.0):
+def cpu_baseline(budget_s=25.0, workload="train"):
     """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same
     workload: whole 1000x600 training iterations until ~budget_s seconds are spent (at least 1)."""
     import copy
@@ -57,7 +57,14 @@ def cpu_baseline(budget_s=25.0):
     from oracle import step as ostep
     from radnet_hip import synth
     C = Config()
-    ot = ostep.OracleTrainer(C, copy.deepcopy(synth.synthetic_weights(seed=3)))
+    if workload == "vgg16":
+        C.network = "vgg16"
+        C.anchor_box_scales = [128, 256, 512]
+        ot = ostep.OracleTrainerVGG(C, copy.deepcopy(synth.synthetic_weights_vgg16(seed=3, n_anchors=9, n_classes=len(C.class_mapping))))
+    elif workload == "cont":
+        ot = ostep.OracleTrainerCont(C, copy.deepcopy(synth.synthetic_weights(seed=3)))
+    else:
+        ot = ostep.OracleTrainer(C, copy.deepcopy(synth.synthetic_weights(seed=3)))
     batch = make_batch(0, 1, 600, 1000)
     np.random.seed(64)
     n, t0 = 0, time.perf_counter()
@@ -72,7 +79,7 @@ def cpu_baseline(budget_s=25.0):
     except Exception:
         cores = os.cpu_count()
     return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d full train iterations (1000x600, 8 GT, NumPy/BLAS oracle, fp32) in %.1f s" % (n, dt)}
+            "sample": "%d full train iterations (%s, 1000x600, 8 GT, NumPy/BLAS oracle, fp32) in %.1f s" % (n, type(ot).__name__, dt)}
 
 
 class _Ptr:
@@ -235,6 +242,108 @@ def collectives_leg(eng, ts, dist, world, n=20):
     return out
 
 
+def _host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count()
+
+
+def bench_predict(args):
+    """BASELINE cfg 3 as a bench line: RADNet's tile path (predict.py:56-122 -> RADNet.py:502-718) over synthetic 2048x2048 tiles.
+    A step = one tile: upload -> device bicubic resize to short side img_size -> preprocess -> base -> RPN -> decode / sort / NMS
+    (<= 300 proposals) -> RoI crop-resize -> classifier on ALL proposals in one pass -> decode + per-class NMS on the host.  The
+    tiles are uint8 arrays in host memory, as the reference's tiler hands them over (the upload is inside the step)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    from faster_rcnn import models as M
+    from faster_rcnn.RADNet import RADNet
+    from faster_rcnn.base_models import resnet50
+    from faster_rcnn.config import Config
+    from radnet_hip import synth
+    C = Config()
+    C.img_size = args.img_size
+    W = synth.synthetic_weights(seed=3)
+    m_rpn, m_cls, m_all, m_rpn3, m_det = M.build_models(C, weights=W, workload="predict")
+    net = RADNet(C, m_rpn3, m_det, resnet50.preprocess)
+    eng = m_rpn3._s.eng
+    if args.tune_cache is not None and os.path.exists(args.tune_cache):
+        eng.load_tuning(args.tune_cache)
+    tiles = [np.random.RandomState(4 + i).randint(0, 256, (2048, 2048, 3)).astype(np.uint8) for i in range(8)]      # BASELINE.md 3: tile seed 4
+    seq = lambda n: [tiles[i % len(tiles)] for i in range(n)]
+    net.device_resident = True
+    net._detect_all(seq(4))                    # plans, launch shapes, graphs ("compile")
+    net._detect_all(seq(4))
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()
+    if args.tune_cache is not None and not os.path.exists(args.tune_cache):
+        eng.save_tuning(args.tune_cache)
+    net._detect_all(seq(max(args.warmup, 2)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dets = net._detect_all(seq(args.steps))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_det = sum(len(v[0]) for d in dets[:len(tiles)] for v in d.values())
+    # ---- roofline leg: the same tiles one at a time on ONE lane, GEMM launches timed from their own dispatch
+    roof = None
+    if args.roofline_steps > 0:
+        for t in tiles[:2]:
+            net._detect(t)
+        torch.cuda.synchronize()
+        eng.ctx.timing(True)
+        eng.ctx.timing_reset()
+        for k in range(args.roofline_steps):
+            net._detect(tiles[k % len(tiles)])
+        torch.cuda.synchronize()
+        per, tot_ms, tot_fl = {}, 0.0, 0.0
+        for cls, name in ((0, "conv_igemm_fwd"), (3, "conv3x3_winograd_layers")):
+            ms, n, fl = eng.ctx.timing_read(cls)
+            if n:
+                per[name] = {"launches_per_step": n / args.roofline_steps, "avg_us": 1e3 * ms / n, "tflops": fl / max(ms, 1e-9) / 1e9}
+                tot_ms += ms
+                tot_fl += fl
+        wms, wn, wfl = eng.ctx.timing_read(3)
+        eng.ctx.timing(False)
+        exec_fl = tot_fl - (wfl * (1.0 - winograd_executed_share(eng)) if wn else 0.0)
+        ach = tot_fl / max(tot_ms, 1e-9) / 1e9
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32; stride-1 3x3 layers of stages 3-5 and rpn_conv1 via Winograd F(4x4,3x3))",
+                "schedule": "one lane, one tile at a time, launches isolated (hipExtLaunchKernelGGL start / stop events; Winograd layers: two marker "
+                            "events around their three kernels); `value` is measured with two tiles in flight",
+                "executed_tflops": exec_fl / max(tot_ms, 1e-9) / 1e9, "executed_frac": exec_fl / max(tot_ms, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                "gemm_ms_per_tile": tot_ms / args.roofline_steps, "gemm_gflop_per_tile": tot_fl / args.roofline_steps / 1e9, "by_kernel": per}
+    fsz = "%dx%d" % (args.img_size, args.img_size)
+    algo = {600: 58.95 + 15 * 29.29, 1000: 162.89 + 15 * 29.29}.get(args.img_size)      # SURVEY.md 8(d) / A.2: RPN pass + 300 RoIs through the head
+    value = args.steps / elapsed
+    out = {"metric": "predict tiles/sec, ResNet50 Faster R-CNN, 2048x2048 tiles", "value": value, "unit": "tiles/sec", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "predict.py tile path (BASELINE cfg 3): 2048x2048 uint8 tile -> %s -> RPN -> NMS (300 proposals) -> RoI crop-resize -> "
+                                  "classifier on all proposals in one pass (GEMM M = 14 700) -> decode + per-class NMS; two tiles in flight" % fsz,
+                      "bench_workload": "predict", "img_size": args.img_size, "anchors": eng.A, "proposals_per_tile": 300, "detections_on_the_8_tiles": n_det,
+                      "launch_shapes": "measured per shape on first use" if not getattr(eng, "shipped_tuning", None) else ", ".join(eng.shipped_tuning),
+                      "algorithmic_gflop_per_tile": algo, "step_tflops_algorithmic": (value * algo / 1e3) if algo else None}}
+    if roof is not None:
+        out["roofline"] = roof
+    if not args.no_cpu_baseline:
+        # the oracle's tile path on one tile (bounded sample: ~500 GFLOP of NumPy / BLAS convolutions)
+        from oracle import dense, glue, resize as oresize, step as ostep
+        t0 = time.perf_counter()
+        small = oresize.resize_bicubic_u8(tiles[0], args.img_size, args.img_size)
+        p, r, F = ostep.rpn_only_forward(W, small)
+        R = glue.rpn_to_roi(p, r, C, True, 300, 0.7)
+        R[:, 2] -= R[:, 0]
+        R[:, 3] -= R[:, 1]
+        glue.spp_decode(R, lambda rois: dense.head_forward(W, F, rois[0].astype(np.float32), len(C.class_mapping))[:2], C)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "tiles/sec", "cores": _host_cores(), "kind": "port",
+                               "sample": "1 tile (2048x2048 -> %s, RPN + 300 proposals through the classifier in 15 chunks of 20, NumPy/BLAS oracle) in %.1f s" % (fsz, dt)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +359,11 @@ def main():
     ap.add_argument("--trainable", choices=("train", "cont"), default="train",
                     help="train: train.py trainability, whole base frozen (the BASELINE metric); cont: cont_train.py, stages 3-4 "
                          "unfrozen in both models (secondary measurement, single GPU)")
+    ap.add_argument("--workload", choices=("train", "cont", "vgg16", "predict"), default="train",
+                    help="train: BASELINE cfg 2, the headline (default).  cont: the same step with cont_train.py trainability (= --trainable "
+                         "cont).  vgg16: BASELINE cfg 5, the train step on the VGG16 base model (9 anchors).  predict: BASELINE cfg 3, "
+                         "RADNet's tile path (RPN -> NMS -> RoI crop-resize -> classifier on 300 RoIs) over 2048x2048 tiles; a step = a tile")
+    ap.add_argument("--img-size", type=int, default=600, help="predict workload: Config.img_size (short side the tile is resized to)")
     ap.add_argument("--tune-cache", default=None,
                     help="file with measured GEMM launch choices: loaded when present (no trial launches), written after warm-up otherwise")
     ap.add_argument("--launch-check", action="store_true",
@@ -257,6 +371,14 @@ def main():
                          "exercises the self-launch path on a machine without GPUs (tests/test_bench_launch.py)")
     args = ap.parse_args()
 
+    if args.workload == "cont":
+        args.trainable = "cont"
+    elif args.trainable == "cont":
+        args.workload = "cont"
+    if args.workload in ("predict", "vgg16", "cont") and args.gpus != 1:
+        raise SystemExit("bench.py --workload %s is a single-GPU line (the multi-GPU metric is the default workload)" % args.workload)
+    if args.workload == "predict":
+        return bench_predict(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process has made no GPU call (torch is imported, nothing
         # initialised) -- it starts N fresh rank processes, one per GPU, relays rank 0's JSON line and exits with their code
@@ -317,6 +439,7 @@ def main():
 
     C = Config()
     cont = args.trainable == "cont"
+    vgg = args.workload == "vgg16"
     if cont:
         if world != 1:
             raise SystemExit("bench.py --trainable cont is single-GPU")
@@ -339,6 +462,13 @@ def main():
                 return _ts.losses()
 
         ts = _Adapter()
+    elif vgg:
+        from radnet_hip import make_engine
+        C.network = "vgg16"
+        C.anchor_box_scales = [128, 256, 512]        # config.py:46: the 3-scale alternative BASELINE cfg 5 names (A = 9)
+        eng = make_engine(C, device_index=local_rank)
+        eng.set_weights(synth.synthetic_weights_vgg16(seed=3, n_anchors=eng.A, n_classes=eng.nc))
+        ts = TrainStep(eng)
     else:
         eng = FasterRCNNEngine(C, device_index=local_rank)
         eng.set_weights(synth.synthetic_weights(seed=3))
@@ -455,7 +585,7 @@ def main():
                 "executed_tflops": exec_fl / max(tot_ms, 1e-9) / 1e9, "executed_frac": exec_fl / max(tot_ms, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "gemm_ms_per_image": tot_ms / args.roofline_steps / args.per_gpu_batch,
                 "gemm_gflop_per_image": tot_fl / args.roofline_steps / args.per_gpu_batch / 1e9, "by_kernel": per}
-        if rank == 0 and not cont and hasattr(eng, "_plan_rpn"):
+        if rank == 0 and not cont and not vgg and hasattr(eng, "_plan_rpn"):
             try:
                 nb0 = args.per_gpu_batch if getattr(ts, "batched", False) else 1       # the mini-batch runs as one program
                 bp0 = eng._plan_base(nb0, args.height, args.width, 0)
@@ -469,15 +599,20 @@ def main():
     if rank == 0:
         n_img = world * args.per_gpu_batch * args.steps
         value = n_img / elapsed
+        algo_gf = ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE
+        if vgg:      # no survey figure for the VGG16 train step: the GEMM flops the step's launches are credited (2MNK, direct convs)
+            algo_gf = roof["gemm_gflop_per_image"] if roof is not None else float("nan")
         out = {
-            "metric": "train images/sec, ResNet50 Faster R-CNN 1000x600",
+            "metric": "train images/sec, %s Faster R-CNN 1000x600" % ("VGG16" if vgg else "ResNet50"),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "full train step (RPN + RoiPoolingConv + classifier head + losses + 2x Adam), ResNet50, %dx%d, "
+            "config": {"workload": "full train step (RPN + RoiPoolingConv + classifier head + losses + 2x Adam), %s, %dx%d, "
                                    "batch=%d per GPU, %s; identical panel and boxes on every rank and step (per-rank RNG seed)"
-                                   % (args.width, args.height, args.per_gpu_batch,
+                                   % ("VGG16 base model (BASELINE cfg 5: 3 anchor scales x 3 ratios, fc head on 20 sampled RoIs per step)" if vgg else "ResNet50",
+                                      args.width, args.height, args.per_gpu_batch,
                                       "stages 3-4 trainable (cont_train.py)" if cont else "base frozen (train.py)"),
+                       "bench_workload": args.workload,
                        "per_gpu_batch": args.per_gpu_batch, "global_batch": world * args.per_gpu_batch, "anchors": eng.A, "n_rois": C.n_rois,
                        "mini_batch_form": ("one layer program, images stacked along the GEMM M dimension" if getattr(ts, "batched", False) and args.per_gpu_batch > 1
                                            else "image by image"),
@@ -486,14 +621,16 @@ def main():
                                     "pipelined over HIP streams: %d prefetch lanes (frozen base forward, %d batches ahead%s), RPN phase, head phase"
                                     % (getattr(eng, "n_side_lanes", 1), LOOK,
                                        ", two consecutive batches' base forwards as one nb=2 program" if getattr(ts, "stack_base", False) and args.per_gpu_batch == 1 else "")),
-                       "reductions": ("ordered (radnet_set_deterministic: no floating-point atomics in the step; bit-identical across runs and schedules)"
-                                      if os.environ.get("RADNET_DETERMINISTIC", "1") != "0" else "fp32 atomics (RADNET_DETERMINISTIC=0)"),
+                       # the contexts' real flag (every lane's), not the environment variable
+                       "reductions": ("ordered (radnet_set_deterministic: no floating-point atomics in the step; bit-identical across runs and "
+                                      "schedules for a given launch-shape table -- another K-split count re-associates the sums)"
+                                      if all(int(eng.lib.radnet_get_deterministic(c.h)) == 1 for c in eng.contexts()) else "fp32 atomics (radnet_set_deterministic off)"),
                        "launch_shapes": (("table %s" % os.path.basename(args.tune_cache)) if have_cache else
                                          ("tuned in situ, shipped (%s) + measured on first use" % ", ".join(eng.shipped_tuning)) if getattr(eng, "shipped_tuning", None)
                                          else "measured per shape on first use"),
                        "base_forward": ("chain kernel, %d workgroups (RADNET_CHAIN=1)" % (getattr(eng, "chain_wgs", 0) or 512)) if getattr(eng, "use_chain", False) else "launch list (hipGraph)",
-                       "algorithmic_gflop_per_image": ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE,
-                       "step_tflops_algorithmic": value / world * (ALGO_GFLOP_CONT if cont else ALGO_GFLOP_PER_IMAGE) / 1e3},
+                       "algorithmic_gflop_per_image": algo_gf,
+                       "step_tflops_algorithmic": value / world * algo_gf / 1e3},
             "losses": losses,
         }
         if roof is not None:
@@ -501,7 +638,7 @@ def main():
         if coll is not None:
             out["config"]["collectives"] = coll
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(workload=args.workload)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -80,6 +80,8 @@ int radnet_force_waves(radnet_ctx* ctx, int waves);
  * therefore last bits -- change from run to run.  Split weight-gradient launches then keep their partial tiles in the
  * workspace (radnet_set_workspace), from its end downwards; launch shapes whose partials do not fit are not used. */
 int radnet_set_deterministic(radnet_ctx* ctx, int enable);
+/* The context's current setting (1 / 0; negative: error) -- what bench.py's `config.reductions` reports. */
+int radnet_get_deterministic(radnet_ctx* ctx);
 /* Per-launch timing of the conv/GEMM kernel families with HIP events on the ctx stream (bench.py's roofline leg).
  * enable=1 starts recording; radnet_timing_read returns accumulated milliseconds and launch count since the last reset for
  * kernel class `cls`: 0 fwd, 1 dgrad, 2 wgrad, 4 dgrad + wgrad in one launch -- each launch timed from its own dispatch

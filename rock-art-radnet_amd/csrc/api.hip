@@ -72,6 +72,8 @@ extern "C" int radnet_set_deterministic(radnet_ctx* ctx, int enable) {
   return RADNET_OK;
 }
 
+extern "C" int radnet_get_deterministic(radnet_ctx* ctx) { return ctx ? (ctx->deterministic ? 1 : 0) : RADNET_ERR_ARG; }
+
 extern "C" int radnet_share_tuning(radnet_ctx* ctx, radnet_ctx* owner) {
   if (!ctx || !owner) return RADNET_ERR_ARG;
   ctx->tuned = owner->tuned;

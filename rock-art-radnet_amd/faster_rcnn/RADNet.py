@@ -386,6 +386,6 @@ def load_radnet(config_path, device_index=0):
     else:
         print('Not a valid base model!')
         sys.exit(1)
-    _, _, model_all, model_rpn, model_detector = models.build_models(C, device_index=device_index)
+    _, _, model_all, model_rpn, model_detector = models.build_models(C, device_index=device_index, workload="predict")      # loads no train-step launch-shape table
     model_all.load_weights(str(C.weights_path).replace('\\', '/'), by_name=True)
     return RADNet(C, model_rpn, model_detector, base_model.preprocess)

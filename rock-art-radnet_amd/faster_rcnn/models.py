@@ -24,11 +24,11 @@ class Adam:
 
 
 class _Shared:
-    def __init__(self, C, device_index=0, weights=None, lr=5e-5, bce_mode=0):
+    def __init__(self, C, device_index=0, weights=None, lr=5e-5, bce_mode=0, workload=None):
         from radnet_hip import synth
         from radnet_hip import make_engine
         self.C = C
-        self.eng = make_engine(C, device_index=device_index, bce_mode=bce_mode, lr=lr)
+        self.eng = make_engine(C, device_index=device_index, bce_mode=bce_mode, lr=lr, workload=workload)
         if weights is None:
             gen = synth.synthetic_weights_vgg16 if C.network == "vgg16" else synth.synthetic_weights
             weights = gen(seed=3, n_anchors=self.eng.A, n_classes=self.eng.nc)
@@ -278,9 +278,9 @@ class AllModel(_ModelBase):
     """Model([img, rois], rpn[:2] + classifier) (train.py:211): exists to save / load every weight."""
 
 
-def build_models(C, device_index=0, weights=None, lr=5e-5, bce_mode=None):
+def build_models(C, device_index=0, weights=None, lr=5e-5, bce_mode=None, workload=None):
     """The four model objects of train.py:199-211 / RADNet.py:748-770 over one shared engine.
     Returns (model_rpn [2 outputs], model_classifier, model_all, model_rpn_predict [3 outputs], model_detector)."""
     from . import losses
-    s = _Shared(C, device_index, weights, lr, losses.BCE_MODE if bce_mode is None else bce_mode)
+    s = _Shared(C, device_index, weights, lr, losses.BCE_MODE if bce_mode is None else bce_mode, workload)
     return RPNModel(s), ClassifierModel(s), AllModel(s), RPNModel(s, with_features=True), DetectorModel(s)

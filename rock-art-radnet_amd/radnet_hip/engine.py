@@ -125,11 +125,16 @@ class FasterRCNNEngine:
 
     NETWORK = "resnet50"
     N_FEATURES = 1024
-    TUNED_PREFIX = "train_"      # which shipped launch-shape tables (radnet_hip/tuned/) this engine's workload is: the pipelined train.py step
+    # Shipped launch-shape tables (radnet_hip/tuned/<workload>_<network>_*.txt) belong to the workload AND network they were tuned in:
+    # the pipelined train.py step of this network by default; an engine built for another workload names it (`workload="predict"`:
+    # RADNet.predict's engine loads no train-step table -- its shapes are measured alone on first use, as they run)
+    WORKLOAD = "train"
     supports_batched = True      # per-GPU mini-batch as one layer program (upload_images / _plan_rpn(nb) / _plan_head(groups))
     feat_len = staticmethod(feat_len)
 
-    def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5, autotune=True):
+    def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=5e-5, autotune=True, workload=None):
+        self.workload = workload or self.WORKLOAD
+        self.TUNED_PREFIX = "%s_%s_" % (self.workload, self.NETWORK)
         if C_cfg.network != self.NETWORK:
             raise L.RadnetError("engine: %s asked to run network %r (use radnet_hip.make_engine)" % (type(self).__name__, C_cfg.network))
         self.C = C_cfg
@@ -535,6 +540,29 @@ class FasterRCNNEngine:
         plan["chain_sub"] = sub                           # keeps the descriptors (and the compiled array) alive
         plan["ops"] = plan["ops"][:first] + [("chain", h)]
         self._chain_plans.append(plan)
+
+    def release_slot(self, slot):
+        """Drop every plan of buffer set `slot` (base / label plans keyed by it, the RPN / classifier plans built on its feature
+        maps) with their buffers and hipGraphs.  TrainStep.validate runs on a buffer set of its own and gives it back here, so a
+        validation pass neither keeps ~0.6 GB per panel size alive between epochs nor counts against the plan cache's limit."""
+        OD = collections.OrderedDict
+        fptrs, drop = set(), []
+        for k in list(self._plans.keys()):
+            if k[0] in ("base", "atgt", "rtgt") and k[-1] == slot:
+                drop.append(k)
+                if k[0] == "base":
+                    fptrs.add(OD.__getitem__(self._plans, k)["F"].data_ptr())
+        for k in list(self._plans.keys()):
+            if k[0] in ("rpn", "head", "head_inf") and len(k) > 4 and (k[3] in fptrs or k[4] in fptrs):
+                drop.append(k)
+        for k in drop:
+            plan = OD.__getitem__(self._plans, k)
+            OD.__delitem__(self._plans, k)
+            self._evict_plan(k, plan)
+
+    def contexts(self):
+        """Every native context of this engine (main + lanes)."""
+        return [self.ctx, self.ctx2, self.ctx3] + [e[1] for e in self._extra_lanes]
 
     def check_chains(self):
         """Raise if any chain launch so far gave up waiting (its feature map was invalid).  Reads the chains' mapped host error

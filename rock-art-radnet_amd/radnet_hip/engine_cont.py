@@ -21,7 +21,7 @@ from .engine import RES_STAGES, Arena, FasterRCNNEngine
 
 
 class ContEngine(FasterRCNNEngine):
-    TUNED_PREFIX = "cont_"       # one lane, other launch mix: the pipelined step's in-situ tables do not apply (measured: -1 %)
+    WORKLOAD = "cont"            # one lane, other launch mix: the pipelined step's in-situ tables do not apply (measured: -1 %)
     supports_batched = False     # cont_train.py's step runs one image at a time (both optimizers move the shared stages)
     # stages 3 / 4 train here: gradients flow through ten Winograd layers and Adam's first steps divide by |g| + 1e-7, so the
     # 15x larger fp32 rounding of F(4x4,3x3) would show in the updates of small-gradient weights -- this mode keeps F(2x2,3x3)

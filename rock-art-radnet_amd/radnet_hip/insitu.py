@@ -84,14 +84,22 @@ def neighbours(key, cur):
         tiles = cdiv(m, a) * cdiv(n, b)
         if tiles * abs(s) >= 16:
             out.append((a, b, -s, w))                      # the other workgroup order (plain / XCD-contiguous)
-    elif abs(s) == 1:
+    else:
         out.append((a, b, -s, w))                          # batched launch: plain / XCD-contiguous numbering of its workgroups
-    if a >= 64:
-        out.append((a, b, s, 12 - w))                      # 4 <-> 8 waves (the 32-row tiles exist with 4 waves only)
+        if w == 4 and (a, b) in ((64, 64), (32, 64), (64, 128), (32, 32)):      # persistent form: z consecutive problems per workgroup
+            zs = [1, 2, 3, 4, 6, 9, 12]
+            i = zs.index(abs(s)) if abs(s) in zs else 0
+            for j in (range(len(zs)) if WIDE else (i - 1, i + 1)):
+                if 0 <= j < len(zs) and zs[j] <= stride:
+                    out.append((a, b, zs[j] if s > 0 else -zs[j], w))
+    if a >= 64 and not (batched and abs(s) > 1):
+        out.append((a, b, s, 12 - w))                      # 4 <-> 8 waves (the 32-row tiles and the persistent form exist with 4 waves only)
     small = npos * c == k and c % BK == 0 and cdiv(m, 64) * cdiv(n, 64) * (stride if batched else 1) <= 6 * 256
     for ta, tb in ((64, 64), (64, 128), (128, 64), (128, 128), (32, 64), (32, 32)):
         if (ta, tb) != (a, b) and not (tb > 64 and n <= 64) and not (ta > 64 and m <= 64) and (ta >= 64 or small):
-            out.append((ta, tb, s if batched else (1 if abs(s) == 1 else s), 4 if ta < 64 else w))
+            persist_ok = (ta, tb) in ((64, 64), (32, 64), (64, 128), (32, 32)) and (4 if ta < 64 else w) == 4
+            sb = s if (abs(s) == 1 or persist_ok) else (1 if s > 0 else -1)
+            out.append((ta, tb, sb if batched else (1 if abs(s) == 1 else s), 4 if ta < 64 else w))
     seen, uniq = set(), []
     for o in out:
         if o not in seen and o != (a, b, s, w):

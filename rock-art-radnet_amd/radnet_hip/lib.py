@@ -148,6 +148,7 @@ def load_library():
         "radnet_force_config": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "radnet_force_waves": (C.c_int, [vp, C.c_int]),
         "radnet_set_deterministic": (C.c_int, [vp, C.c_int]),
+        "radnet_get_deterministic": (C.c_int, [vp]),
         "radnet_timing_enable": (C.c_int, [vp, C.c_int]),
         "radnet_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
         "radnet_timing_reset": (C.c_int, [vp]),

@@ -101,6 +101,13 @@ class TrainStep:
         # RADNET_STACK_BASE=1 switches it on.
         self.stack_base = os.environ.get("RADNET_STACK_BASE", "0") == "1" and getattr(eng, "supports_batched", False)
         self.skipped_head_steps = 0
+        # per image of the last step: positive RoIs among the sampled ones (get_selected_samples' second value, what train.py:385-386
+        # appends to rpn_accuracy_for_epoch), 0 for an image whose classifier step was skipped (train.py:378-380), None for an image
+        # the labeller dropped (the reference's generator never yields it)
+        self.last_n_pos = []
+        self.last_took_head = []    # per image of the last step: its classifier step ran (n_pos may be 0 for one on background RoIs only)
+        self._loss_log = None       # start_loss_log(): device rows [rpn_cls, rpn_regr, det_cls, det_regr, det_acc] per classifier step
+        self._loss_log_n = 0
         self.dropped_images = 0     # images whose anchor labelling raised (reference: sample skipped, utils.py:461-465)
         self.on_drop = None         # optional callback(sample, exception); default: one line on stderr, like the reference's print
         self.last = None
@@ -123,6 +130,29 @@ class TrainStep:
                 work.wait()
         self.eng.adam(self.eng.head_arena, grad_scale=1.0 / ntot)
         self.eng.refresh_head_shift()
+
+    def start_loss_log(self, capacity):
+        """Keep the five losses of every classifier step from here on in a device buffer (one row per image that took a head step,
+        in order): what train.py:405-417 writes into losses[iter_num] -- read back ONCE per epoch (read_loss_log) instead of with a
+        host synchronisation per iteration, so the pipelined step keeps running ahead of the host."""
+        self._loss_log = torch.zeros(max(int(capacity), 1), 5, dtype=torch.float32, device=self.eng.dev)
+        self._loss_log_n = 0
+
+    def read_loss_log(self):
+        """(n, 5) host array of the rows logged since start_loss_log (one device sync)."""
+        if self._head_last is not None:
+            self._head_last.synchronize()
+        else:
+            torch.cuda.synchronize(self.eng.dev)
+        return self._loss_log[:self._loss_log_n].cpu().numpy() if self._loss_log is not None else np.zeros((0, 5), np.float32)
+
+    def _log_losses(self, rpn_row, det_row):
+        if self._loss_log is None or self._loss_log_n >= self._loss_log.shape[0]:
+            return
+        row = self._loss_log[self._loss_log_n]
+        self.eng._copy(row[:2], rpn_row[:2])
+        self.eng._copy(row[2:5], det_row[:3])
+        self._loss_log_n += 1
 
     def flush(self):
         """End of a pipelined run: the main stream waits for the head lane, and a head update still in flight
@@ -193,6 +223,10 @@ class TrainStep:
             out["total"] = out["rpn_cls"] + out["rpn_regr"] + out["det_cls"] + out["det_regr"]
             out["per_sample"] = [dict(rpn_cls=float(r[i, 0]), rpn_regr=float(r[i, 1]), det_cls=float(d[i, 0]), det_regr=float(d[i, 1]), det_acc=float(d[i, 2]),
                                       n_pos=int(n_pos_all[i])) for i in range(len(used))]
+        if getattr(eng, "_chain_plans", None):
+            eng.check_chains()
+        if hasattr(eng, "release_slot"):
+            eng.release_slot(self.VAL_SLOT)       # the validation pass's buffer set does not outlive it (plans, buffers, graphs)
         return out
 
     def _gt(self, s):
@@ -430,6 +464,8 @@ class TrainStep:
         mark("B: next batch's upload + base + rpn forward enqueued")
         # ---- phase D, host half: RoI class codes -> sample selection on the host RNG (the step's host sync)
         picks = []
+        self.last_n_pos = [None] * nloc
+        self.last_took_head = [False] * nloc
         for i in range(nloc):
             if st["roi"][i] is None:                               # dropped by the labeller (see _rpn_phase): not a head skip
                 picks.append(None)
@@ -440,9 +476,12 @@ class TrainStep:
             kept = np.nonzero(cls >= 0)[0]
             if n <= 0 or len(kept) == 0:                           # calc_iou -> None: the reference skips the head step
                 self.skipped_head_steps += 1
+                self.last_n_pos[i] = 0
                 picks.append(None)
                 continue
-            sel_k, _ = E.select_samples(cls[kept], eng.bg, C.n_rois)
+            sel_k, n_pos = E.select_samples(cls[kept], eng.bg, C.n_rois)
+            self.last_n_pos[i] = int(n_pos)
+            self.last_took_head[i] = True
             picks.append((P, kept[np.asarray(sel_k, dtype=np.int64)]))
             mark("D: samples selected")
             if self.capture is not None:
@@ -488,6 +527,8 @@ class TrainStep:
                 eng.head_forward(hp, training=True, loss_out=self._det_l[slot], group_live=[p is not None for p in picks])
                 eng.set_accumulate(hp["bwd"], False, prezeroed=True)
                 eng.head_backward(hp, accumulate=True, loss_out=slots, on_part=exchange if bucketed else None)
+                for i in det_rows:
+                    self._log_losses(self._rpn_l[slot][i], self._det_l[slot][i])
             for i, bp in enumerate(st["plans"] if not st.get("stacked") else []):
                 if picks[i] is None:
                     continue
@@ -500,6 +541,7 @@ class TrainStep:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head], on_part=exchange)
                 else:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head])
+                self._log_losses(self._rpn_l[slot][i], self._det_l[slot][n_head])
                 n_head += 1
             if n_head > 0 or self.world > 1:
                 self._finish_head_update()               # only still pending when every local image skipped its head phase

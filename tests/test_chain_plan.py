@@ -110,3 +110,28 @@ def test_unsupported_ops_are_refused_with_a_message():
     ops[0].conv.c = 4                                   # the 4-channel stem is not a chain item
     rc, *_, err = check(ops)
     assert rc == -3 and "chain" in err
+
+
+def test_buffer_reuse_inside_a_chain_is_refused():
+    """The counters order a reader behind its producer and nothing else (consumers read through ordinary per-XCD L2 loads, safe
+    only while every tensor is written once per launch): a list that writes a tensor twice, or writes one an earlier op read
+    (ping-pong activations), has WAW / WAR hazards -- radnet_chain_check / radnet_chain_build refuse it (round-3 advice)."""
+    ops = base_ops(300, 500)
+    rc, *_ = check(ops)
+    assert rc == 0
+    # an output written twice
+    ops = base_ops(300, 500)
+    ops[3].conv.y = ops[0].conv.y
+    rc, *_, err = check(ops)
+    assert rc == -3 and "re-use" in err, err
+    # ping-pong: a later op writes the tensor the first op read
+    ops = base_ops(300, 500)
+    ops[2].conv.y = ops[0].conv.x
+    rc, *_, err = check(ops)
+    assert rc == -3 and "re-use" in err, err
+    # a Winograd layer whose product buffer is an earlier conv's output
+    ops = base_ops(600, 1000)
+    w = next(o for o in ops if o.kind == L.OP_WINO)
+    w.p[3] = ops[0].conv.y
+    rc, *_, err = check(ops)
+    assert rc == -3 and "re-use" in err, err

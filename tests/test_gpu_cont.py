@@ -78,12 +78,26 @@ def test_rpn_phase_gradients_reach_stages_3_4(setup):
     torch.cuda.synchronize()
     assert fro_err(bp["F"].cpu().numpy(), F) < 1e-4
     assert fro_err(bp["dF"].cpu().numpy().reshape(F.shape), dF * (F > 0)) < 1e-3
+    # The gradient of res3a crosses thirty ReLU masks.  Where a pre-activation lands within fp32 rounding of zero the device's mask
+    # and the oracle's differ, and WHICH elements do depends on the summation order of the launch shapes in use (round 4: the
+    # 32-row tiles moved res3a_branch2a from under 2e-3 to 2.9e-3 against the oracle's own masks).  The strict comparison therefore
+    # runs the oracle's backward on the DEVICE's masks (its cached post-ReLU outputs replaced by the device's, which agree to
+    # 1e-4); against the oracle's own masks a looser bound stays as a gross-error check.
+    caches_dev = copy.deepcopy(caches)
+    for co, B in zip(caches_dev[4:], bp["blocks"]):                 # conv1, three stage-2 blocks, then stages 3-4 in order
+        for part, buf in (("a", B["a"]), ("b", B["b"]), ("c", B["out"])):
+            dev_y = buf.cpu().numpy()
+            assert dev_y.shape == co[part]["y"].shape and fro_err(dev_y, co[part]["y"]) < 1e-4
+            co[part]["y"] = dev_y
+    g_dev = dense.base_backward(P, caches_dev, dF)
     worst = 0.0
     for n in eng.s34_names:
         c = eng.convs[n]
-        e = max(fro_err(c.dweight.cpu().numpy(), g_ref[n]["kernel"].reshape(-1, c.cout)), fro_err(c.dbias.cpu().numpy(), g_ref[n]["bias"]))
+        e = max(fro_err(c.dweight.cpu().numpy(), g_dev[n]["kernel"].reshape(-1, c.cout)), fro_err(c.dbias.cpu().numpy(), g_dev[n]["bias"]))
         worst = max(worst, e)
-        assert e < 2e-3, (n, e)
+        assert e < 1e-3, (n, e)
+        e_own = max(fro_err(c.dweight.cpu().numpy(), g_ref[n]["kernel"].reshape(-1, c.cout)), fro_err(c.dbias.cpu().numpy(), g_ref[n]["bias"]))
+        assert e_own < 1e-2, (n, e_own)
     assert fro_err(eng.convs["rpn_conv1"].dweight.cpu().numpy(), g_ref["rpn_conv1"]["kernel"].reshape(-1, 512)) < 1e-3
     # leave the arenas as a step would: cleared
     eng.adam(eng.rpn_arena)

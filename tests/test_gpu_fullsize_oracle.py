@@ -151,11 +151,26 @@ def test_cfg2_full_step_1000x600_vs_oracle():
     gh = detail["g_head"]
     l_det = eng.det_losses.cpu().numpy()
     assert abs(l_det[0] - ref[2]) < 2e-3 * abs(ref[2]) and abs(l_det[1] - ref[3]) < 2e-3 * abs(ref[3]) + 1e-5
+    # The stage-5 gradients cross up to eight ReLU masks; where an activation lands within rounding of zero the device's mask
+    # and the oracle's differ in single elements, which moves isolated gradient entries by whole terms (~1e-4 of the largest
+    # gradient) -- not rounding noise of one sum.  So the oracle's backward is evaluated ON THE DEVICE'S MASKS (its cached
+    # post-ReLU outputs replaced by the device's, the way proposals are compared on the device's own tensors): what is left is
+    # summation order, and the per-channel floor is the checker's default 1e-3 again (round 3 had raised it to 1e-2 here).
+    pc_o, pr_o, cache_o = dense.head_forward(P, F_ref, rois, 7)
+    for co, B in zip(cache_o["blocks"], hp["blocks"]):
+        for part, buf in (("a", B["a"]), ("b", B["b"]), ("c", B["out"])):
+            dev_y = buf.cpu().numpy()
+            assert dev_y.shape == co[part]["y"].shape
+            assert check(dev_y, co[part]["y"], 1e-3) < 1e-3
+            co[part]["y"] = dev_y
+    _, dpc_o = dense.class_loss_cls(Y1[None], pc_o)
+    _, dpr_o = dense.smooth_l1_masked(Y2[None], pr_o, 4 * 6)
+    gh_dev, _ = dense.head_backward(P, cache_o, dpc_o, dpr_o)
     for name in eng.head_conv_names:
         c = eng.convs[name]
-        # floor 1e-2: res5a's kernels see gradients that crossed two blocks' ReLU masks -- single mask elements differ from the
-        # oracle's (an activation within rounding of zero), which moves isolated entries by ~1e-4 of the largest gradient
-        # (max-norm measured 2e-5 ... 2e-4; which entries depends on the launch shapes' summation order)
+        assert check(c.dweight.cpu().numpy(), gh_dev[name]["kernel"].reshape(-1, c.cout), 2e-3) < 2e-3, name
+        assert check(c.dbias.cpu().numpy(), gh_dev[name]["bias"], 2e-3) < 2e-3, name
+        # against the oracle's own masks the max-norm and RMS criteria hold as well; only the per-channel one needs the mask alignment
         assert check(c.dweight.cpu().numpy(), gh[name]["kernel"].reshape(-1, c.cout), 2e-3, floor=1e-2) < 2e-3, name
         assert check(c.dbias.cpu().numpy(), gh[name]["bias"], 2e-3) < 2e-3, name
     dk, db = eng.dense_dw.cpu().numpy(), eng.dense_db.cpu().numpy()

@@ -16,10 +16,14 @@ def _tool():
 def _valid(key, a, b, s, w):
     """What csrc/conv_mfma.hip (run_igemm / run_wgrad) and radnet_tune_load accept for a measured shape."""
     kind, m, n, k, c, npos, stride = key
-    assert a in (64, 128) and b in (64, 128) and w in (4, 8) and s != 0 and abs(s) <= 64, (key, a, b, s, w)
     wgrad = (kind & 7) in (2, 3)
-    if kind >= 8:
+    small = (a, b) in ((32, 64), (32, 32))                           # round 4: 32-row tiles of the forward / data-gradient kernel, 4 waves
+    assert (small and not wgrad and w == 4) or (a in (64, 128) and b in (64, 128)), (key, a, b, w)
+    assert w in (4, 8) and s != 0 and abs(s) <= 64, (key, a, b, s, w)
+    if kind >= 8 and wgrad:
         assert s in (1, -1), (key, s)                               # a batch is its own source of workgroups; -1: XCD-contiguous numbering
+    if kind >= 8 and not wgrad and abs(s) > 1:                       # persistent form: |s| consecutive problems per workgroup
+        assert abs(s) <= 12 and abs(s) <= stride and w == 4 and (a, b) in ((64, 64), (32, 64), (64, 128), (32, 32)), (key, a, b, s, w)
     if wgrad:
         assert c % a == 0 and (s >= 1 or kind >= 8) and w == 4, (key, a, s, w)
         nmt = (m + 31) // 32
@@ -28,7 +32,7 @@ def _valid(key, a, b, s, w):
     else:
         if b > 64:
             assert n > 64, (key, b)
-        if abs(s) > 1:
+        if abs(s) > 1 and kind < 8:
             assert ((k + 31) // 32) // abs(s) >= 2, (key, s)          # a K slice holds at least two k tiles
 
 
@@ -39,7 +43,8 @@ def test_shipped_tables_parse_and_hold_valid_shapes():
     seen = {}
     for path in files:
         name = os.path.basename(path)
-        assert name.startswith(("train_", "cont_")), name           # an engine loads the tables of its workload (engine.TUNED_PREFIX)
+        # an engine loads the tables of its workload AND network (engine.TUNED_PREFIX = "<workload>_<network>_")
+        assert name.startswith(("train_resnet50_", "train_vgg16_", "cont_resnet50_", "predict_resnet50_", "predict_vgg16_")), name
         tab, header = T.read_table(path)
         assert header is not None and header.startswith("# radnet tuned GEMM launch shapes v2") or open(path).readline().startswith("# radnet tuned GEMM launch shapes v2")
         assert len(tab) >= 10, (name, len(tab))

@@ -13,8 +13,7 @@ FMA epilogues on the device against the oracle's float64 / BLAS sums), as ONE ch
 that pass through ReLU masks differ from the oracle's by whole terms wherever an activation lands within rounding of zero on one
 side only (measured: 2e-5 ... 2e-4 of the largest gradient for res5a's kernels at 1000x600, against 5e-7 for the layers behind
 no such mask) -- in a channel whose own gradients are that small the per-channel bound must start from that level.  One-dimensional arrays (bias
-gradients) have no channel axis: criteria 1 and 3.  RADNET_TOL_REPORT=1 prints the three measured ratios per call instead of
-asserting (used once per round on the GPU box to see how far below the bounds the kernels sit; profiles/r03_tolerance_report.txt)."""
+gradients) have no channel axis: criteria 1 and 3.  RADNET_TOL_REPORT=1 also prints the three measured ratios per call (used once per round on the GPU box to see how far below the bounds the kernels sit; profiles/r03_tolerance_report.txt)."""
 import os
 
 import numpy as np
@@ -48,9 +47,8 @@ def check(a, b, tol, what="", floor=FLOOR):
         what = "%s:%d" % (os.path.basename(f.f_code.co_filename), f.f_lineno)
     max_ratio, chan, rms_ratio = measure(a, b, floor)
     worst = float(chan.max()) if chan is not None else float("nan")
-    if _REPORT:
+    if _REPORT:          # report mode prints AND asserts (round-3 advice: a variable left set must not make the suite pass vacuously)
         print("[tol] %-44s tol %.0e  max-norm %.2e  worst-channel %.2e  rms %.2e (bound %.0e)" % (what, tol, max_ratio, worst, rms_ratio, RMS_FRACTION * tol))
-        return max_ratio
     assert max_ratio < tol, "%s: max-norm error %.3e >= %.1e" % (what, max_ratio, tol)
     if chan is not None:
         c = int(chan.argmax())
