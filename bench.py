@@ -225,7 +225,29 @@ def collectives_leg(eng, ts, dist, world, n=20):
     on the head communicator)."""
     if dist is None:
         return None
-    out = {"per_step": "AR#1 rpn arena (1 call) + AR#2 head arena (3 block buckets + tail)", "world": world}
+    if getattr(ts, "native_comm", False):
+        # round 4: the library's own RCCL binding (radnet_allreduce_grads): AR#1 in line on the main lane, AR#2 one call on the head
+        # communicator's stream
+        import contextlib
+        from radnet_hip import native as N
+        out = {"per_step": "AR#1 rpn arena (1 ncclAllReduce on the main lane) + AR#2 head arena (1 ncclAllReduce on its own stream, deferred update)",
+               "path": "radnet_allreduce_grads (RCCL bound by the library; torch.distributed only for the rendezvous)", "world": world}
+        for name, arena, ctx, stream in (("ar1_rpn", eng.rpn_arena, ts._main_ctx, None), ("ar2_head", eng.head_arena, ts._comm_ctx, ts._comm_stream)):
+            buf = torch.zeros_like(arena.g)
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                for _ in range(3):
+                    N.allreduce(eng, buf, ctx=ctx)
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    N.allreduce(eng, buf, ctx=ctx)
+                e1.record()
+                e1.synchronize()
+            out[name] = {"bytes": int(arena.n * 4), "ms_alone": e0.elapsed_time(e1) / n}
+        return out
+    out = {"per_step": "AR#1 rpn arena (1 call) + AR#2 head arena (3 block buckets + tail)", "path": "torch.distributed", "world": world}
     for name, arena, group in (("ar1_rpn", eng.rpn_arena, ts.group), ("ar2_head", eng.head_arena, ts.group_head)):
         buf = torch.zeros_like(arena.g)
         for _ in range(3):

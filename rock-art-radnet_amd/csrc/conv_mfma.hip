@@ -1251,8 +1251,10 @@ struct PairMap {
   unsigned wx, wy;              // wgrad grid (x, y); z = n_w / (wx * wy)
 };
 
+// ABM: rows of the data gradient's output tile (64, or 32 since round 4: M = 980 rows are 31 tiles of 32 with no K slices to reduce)
+template <int ABM>
 __global__ void __launch_bounds__(NTHREADS) conv_bwd_pair_kernel(GemmArgs ga, WgradArgs gw, PairMap pm) {
-  constexpr int kLds = igemm_lds_floats<64, 64, 1>() > wgrad_lds_floats<64, 64>() ? igemm_lds_floats<64, 64, 1>() : wgrad_lds_floats<64, 64>();
+  constexpr int kLds = igemm_lds_floats<ABM, 64, 1>() > wgrad_lds_floats<64, 64>() ? igemm_lds_floats<ABM, 64, 1>() : wgrad_lds_floats<64, 64>();
   __shared__ __attribute__((aligned(16))) float lds[kLds];
   const unsigned b = blockIdx.x, both = 2u * (pm.n_a < pm.n_w ? pm.n_a : pm.n_w);
   bool is_a;
@@ -1266,7 +1268,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_bwd_pair_kernel(GemmArgs ga, Wg
   }
   if (is_a) {
     const unsigned by = idx / pm.ax;
-    conv_igemm_body<64, 64, 1, false, 4>(ga, lds, idx - by * pm.ax, by, 0u, pm.ax);
+    conv_igemm_body<ABM, 64, 1, false, 4>(ga, lds, idx - by * pm.ax, by, 0u, pm.ax);
   } else {
     const unsigned plane = pm.wx * pm.wy, bz = idx / plane, r = idx - bz * plane, by = r / pm.wx;
     conv_wgrad_body<64, 64>(gw, lds, r - by * pm.wx, by, bz);
@@ -1437,6 +1439,7 @@ void launch_igemm(hipStream_t st, const GemmArgs& g, const TileChoice& tc, int n
 // ctx->pair_capture is set; the measuring launches of a first, autotuned call are issued as usual (PairPause).
 struct PairCapture {
   bool have_a = false, a_ok = false, have_w = false, w_ok = false;
+  int a_bm = 64;
   GemmArgs ga;
   unsigned ax = 0, ay = 0;
   WgradArgs gw;
@@ -1519,7 +1522,8 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     if (ctx->pair_capture != nullptr) {
       PairCapture* pc = (PairCapture*)ctx->pair_capture;
       pc->have_a = true;
-      pc->a_ok = bmode == 1 && !smallc && t.bm == 64 && t.bn == 64 && t.waves != 8 && g.batch <= 1;
+      pc->a_ok = bmode == 1 && !smallc && (t.bm == 64 || t.bm == 32) && t.bn == 64 && t.waves != 8 && g.batch <= 1;
+      pc->a_bm = t.bm;
       pc->ga = g;
       pc->a_slab_bytes = tb ? (uint64_t)tb->n_slots * t.bm * t.bn * sizeof(float) : 0;
       pc->ax = g.units != nullptr ? (unsigned)n_units : (unsigned)radnet_cdiv(g.M, t.bm);
@@ -1565,7 +1569,7 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
     const bool for_pair = pause.saved != nullptr && bmode == 1 && !smallc && g.batch <= 1;
     for (int c = 0; c < 6; ++c) {
       if ((cand[c][1] > 64 && g.N <= 64) || (cand[c][0] > 64 && g.M <= 64)) continue;
-      if (for_pair && (cand[c][0] != 64 || cand[c][1] != 64)) continue;
+      if (for_pair && ((cand[c][0] != 64 && cand[c][0] != 32) || cand[c][1] != 64)) continue;
       if (cand[c][0] < 64 && (smallc || tiles64 > 6 * kNumCU)) continue;
       const long long tiles = (long long)radnet_cdiv(g.M, cand[c][0]) * radnet_cdiv(g.N, cand[c][1]);
       for (int s : chunks) {
@@ -2032,7 +2036,8 @@ static int run_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d, int batch, long
   auto it = ctx->tuned->find(key);
   if (ctx->force_a > 0) {
     bmk = ctx->force_a; bn = ctx->force_b; splits = ctx->force_splits < 1 ? 1 : ctx->force_splits;
-    if (bmk < 64 || bn < 64) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced tile %dx%d (the weight-gradient kernel has 64 / 128 tiles)", bmk, bn);
+    if (bmk < 64) bmk = 64;      // the 32-row tiles are the forward / data-gradient kernel's: a forced 32x64 leaves the weight gradient at 64x64
+    if (bn < 64) bn = 64;        // (radnet_conv_bwd then pairs a 32x64 data gradient with a 64x64 weight gradient)
     if (d->c % bmk) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_wgrad: forced k tile %d does not divide c=%d", bmk, d->c);
   } else if (it != ctx->tuned->end()) {
     bmk = it->second.a; bn = it->second.b; splits = it->second.splits;
@@ -2147,7 +2152,8 @@ extern "C" int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   }
   PairMap pm{pc.ax * pc.ay, pc.wx * pc.wy * pc.wz, pc.ax, pc.ay, pc.wx, pc.wy};
   radnet_timing_arm(ctx);
-  RADNET_LAUNCH(conv_bwd_pair_kernel, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, pc.ga, pc.gw, pm);
+  if (pc.a_bm == 32) RADNET_LAUNCH(conv_bwd_pair_kernel<32>, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, pc.ga, pc.gw, pm);
+  else RADNET_LAUNCH(conv_bwd_pair_kernel<64>, dim3(pm.n_a + pm.n_w), dim3(NTHREADS), 0, ctx->stream, ctx->arm0, ctx->arm1, pc.ga, pc.gw, pm);
   RADNET_CHECK_LAUNCH(ctx, "conv_bwd_pair");
   radnet_timing_end_armed(ctx, 4, pc.flops);
   return RADNET_OK;

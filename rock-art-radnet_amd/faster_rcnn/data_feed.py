@@ -275,13 +275,83 @@ class BackgroundFeed:
         self._thread.join(timeout=5)
 
 
-def run_training(ts, feed, n_steps, lookahead=3, on_step=None):
+def _insitu_tables(ts, first_batch, lookahead, next_batch, budget_s, cache_dir, dist_group, log):
+    """run_training(tune=True): launch shapes tuned IN SITU for a job whose shapes no shipped table knows (radnet_hip/insitu.py).
+    One table per (workload, network, panel size, images per step, device) under the user's cache directory: found -> loaded
+    (rank 0 reads it, every rank loads the same text); missing -> walked over the first steps of THIS job, bounded by budget_s,
+    rank 0 deciding for all ranks (every rank keeps stepping: the gradient exchanges stay symmetric), then written by rank 0.
+    Returns the number of training steps the walk consumed."""
+    import os
+    import tempfile
+    import torch
+    from radnet_hip import insitu
+    eng = ts.eng
+    H, W = first_batch[0]["img"].shape[:2]
+    comm = insitu.NoComm()
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(dist_group) > 1:
+            comm = insitu.DistComm(dist, dist_group)
+    except Exception:
+        pass
+    dev_name = torch.cuda.get_device_name(eng.dev) if torch.cuda.is_available() else "cpu"
+    path = insitu.cache_path(getattr(eng, "NETWORK", "net"), getattr(eng, "workload", "train"), H, W, len(first_batch), dev_name, cache_dir)
+    shipped = any("%dx%d_batch%d" % (H, W, len(first_batch)) in n for n in getattr(eng, "shipped_tuning", []))
+    text = None
+    if comm.rank == 0 and not shipped and os.path.exists(path):
+        text = open(path).read()
+    shipped, text = comm.bcast((shipped, text))
+    if shipped:
+        return 0                                    # this very workload has a shipped table: loaded when the engine was built
+    if text is not None:
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write(text)
+        eng.load_tuning(f.name)
+        os.remove(f.name)
+        log("radnet: in-situ table %s loaded" % path)
+        return 0
+    consumed = [0]
+    if comm.rank == 0:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+    before, after, n_changed, left = insitu.tune_job(ts, next_batch, path, steps_done=lambda n: consumed.__setitem__(0, consumed[0] + n),
+                                                     lookahead=lookahead, budget_s=budget_s, comm=comm, log=log,
+                                                     measure=getattr(ts, "insitu_measure", None), sync=getattr(ts, "insitu_sync", None),
+                                                     steps=getattr(ts, "insitu_steps", 100))
+    log("radnet: launch shapes tuned in situ over %d steps: %.1f -> %.1f us per step (%d changes); table: %s" % (consumed[0], before, after, n_changed, path))
+    return consumed[0], left
+
+
+def run_training(ts, feed, n_steps, lookahead=3, on_step=None, tune=None, tune_budget_s=120.0, tune_cache_dir=None, dist_group=None, log=None):
     """Drive a TrainStep from a sample iterator, one sample per batch, announcing `lookahead` batches ahead (the pipelined
     step).  With lookahead > 0 the feed must draw from its own RandomState (see module docstring).  Returns the number of
-    steps run."""
+    steps run.
+    tune (default: the environment's RADNET_INSITU=1): tune the launch shapes in situ over the first steps of the job when neither
+    a shipped nor a cached table knows this (network, panel size, batch, device) -- see _insitu_tables; the steps the walk runs are
+    training steps of this job and count towards n_steps."""
+    import os
     it = iter(feed)
     window = []
     done = 0
+    log = log or (lambda m: __import__("sys").stderr.write(m + "\n"))
+    if tune is None:
+        tune = os.environ.get("RADNET_INSITU", "0") == "1"
+    if tune and hasattr(ts, "eng") and hasattr(ts.eng, "load_tuning"):
+        try:
+            first = [next(it)]
+        except StopIteration:
+            return 0
+        pending = [first]
+
+        def next_batch():
+            return pending.pop(0) if pending else [next(it)]
+
+        got = _insitu_tables(ts, first, lookahead, next_batch, tune_budget_s, tune_cache_dir, dist_group, log)
+        if isinstance(got, tuple):
+            done, left = got
+            window.extend(left)                     # batches the walk had announced but not yet stepped
+        window[:0] = pending
+        if on_step is not None and done:
+            on_step(done, ts)
 
     def fill():
         while len(window) < lookahead + 1:

@@ -109,56 +109,112 @@ def neighbours(key, cur):
 
 
 
-def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, gain=0.0025, wide=False, n_prime=18, log=print):
+class NoComm:
+    """Single process: nothing to agree on."""
+    rank = 0
+
+    def bcast(self, obj):
+        return obj
+
+
+class DistComm:
+    """Ranks of a torch.distributed job walk the table TOGETHER: every step of the workload carries the gradient exchanges, so all
+    ranks must run the same number of steps with the same control flow.  Rank 0's table, rank 0's clock and rank 0's verdict on
+    every candidate are broadcast (a few bytes per decision); the other ranks apply the same tables -- any launch shape computes
+    the same convolution, so the replicas stay consistent -- and end the walk holding rank 0's table."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+        self.rank = dist.get_rank(group)
+
+    def bcast(self, obj):
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0 if self.group is None else self.dist.get_global_rank(self.group, 0), group=self.group)
+        return box[0]
+
+
+def cache_path(network, workload, H, W, per_batch, device_name, cache_dir=None):
+    """Where a job's in-situ table lives: one file per (workload, network, panel size, images per step, device)."""
+    import os
+    import re
+    d = cache_dir or os.environ.get("RADNET_TUNE_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "radnet_hip", "tuned")
+    dev = re.sub(r"[^A-Za-z0-9]+", "-", device_name or "gpu").strip("-")
+    return os.path.join(d, "%s_%s_%dx%d_batch%d_%s.txt" % (workload, network, H, W, per_batch, dev))
+
+
+def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, gain=0.0025, wide=False, n_prime=18, log=print,
+         measure=None, comm=None, sync=None, only_new=False):
     """Walk `eng`'s launch-shape table against the throughput of the workload.
+    measure(n) -> microseconds per step over n steps (default: run(20) untimed, then run(n) between two device synchronisations);
+    comm: NoComm / DistComm (multi-rank jobs: rank 0 decides, see DistComm); sync(): device synchronisation (default torch's).
+    only_new: walk only the shapes the engine measures during the first n_prime steps of THIS call (a job whose engine already
+    holds shipped tables for other workloads: entries the job never launches are left alone).
 
     run(n): enqueue n steps of the workload (the caller's loop over TrainStep.step with its lookahead); flush(): drain it.
     The engine must come without tables of its own (RADNET_SHIPPED_TUNING=0) and must not have run the workload yet: the shapes
     it measures itself during the first n_prime steps are the shapes that are walked -- a change to a shape the workload never
     launches can only "win" by noise.  start: path of a table whose entries for those shapes replace the measured ones first.
     out: the table is written there after every kept change.  Returns (us_per_step_before, us_per_step_after, changes)."""
-    import torch
     global WIDE
     WIDE = bool(wide)
+    comm = comm or NoComm()
+    root = comm.rank == 0
+    if sync is None:
+        import torch
+        sync = torch.cuda.synchronize
     t_begin = time.perf_counter()
-    tmp = out + ".tmp"
+    tmp = "%s.tmp%d" % (out, comm.rank)
+    own_measure = measure
 
     def measure(n=steps):
+        if own_measure is not None:
+            return comm.bcast(own_measure(n))
         run(20)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         run(n)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e6
+        sync()
+        return comm.bcast((time.perf_counter() - t0) / n * 1e6)      # rank 0's clock decides for everybody
 
     def apply(tab, header):
         flush()
-        torch.cuda.synchronize()
+        sync()
         write_table(tmp, tab, header)
         eng.load_tuning(tmp)
         eng._graphs.clear()                  # programs run eagerly once (unit tables are built), then are recorded again
         run(n_prime)
-        torch.cuda.synchronize()
+        sync()
 
+    if not root:
+        log = lambda *a: None
+    known = set()
+    if only_new:
+        eng.save_tuning(tmp)
+        known = set(read_table(tmp)[0])
     run(n_prime)
-    torch.cuda.synchronize()
+    sync()
     eng.save_tuning(tmp)
     tab, header = read_table(tmp)
+    walk = comm.bcast(sorted(k for k in tab if k not in known)) if only_new else None
     if start:
         used = set(tab)
         start_tab, _ = read_table(start)
         tab.update({k: v for k, v in start_tab.items() if k in used})
+    tab, header = comm.bcast((tab, header))  # the walk starts from rank 0's measured shapes on every rank
+    if start or not isinstance(comm, NoComm):   # (every rank of a job re-applies, also rank 0: apply() runs steps, and steps carry collectives)
         apply(tab, header)
     best = min(measure(), measure())
     log("start: %d entries, step %.1f us (%.1f steps/s)" % (len(tab), best, 1e6 / best))
     start_us = best
     changed = []
     n_tried = 0
-    out_of_time = lambda: time.perf_counter() - t_begin > budget_s
+    out_of_time = lambda: comm.bcast(time.perf_counter() - t_begin > budget_s)
     for p in range(passes):
         n_acc = 0
         # longest launches first: ms x (how often is unknown) -- the per-launch time is the proxy
         for key in sorted(tab, key=lambda kk: -tab[kk][3]):
+            if walk is not None and key not in walk:
+                continue
             cur = list(tab[key])
             for cand in neighbours(key, cur):
                 if out_of_time():
@@ -186,7 +242,8 @@ def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, 
                             best = ref
                 except RuntimeError as e:      # the step's state is unknown after a failed launch: stop with what is kept so far
                     log("  %s -> %s: %s -- stopping" % (key, cand, str(e).splitlines()[0][:160]))
-                    write_table(out, tab, header)
+                    if root:
+                        write_table(out, tab, header)
                     raise
                 log("  %-44s %s -> %s : %.1f / %.1f us vs %.1f %s" % (key, tuple(cur[:3] + [cur[4]]), cand, t1, t2, best, "KEPT" if ok else ""))
                 if ok:
@@ -195,7 +252,8 @@ def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, 
                     best = max(t1, t2)
                     n_acc += 1
                     changed.append((key, cand))
-                    write_table(out, tab, header)
+                    if root:
+                        write_table(out, tab, header)
             if out_of_time():
                 log("budget reached")
                 break
@@ -204,7 +262,32 @@ def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, 
             break
     apply(tab, header)
     end_us = min(measure(2 * steps), measure(2 * steps))
-    write_table(out, tab, header)
+    if root:
+        write_table(out, tab, header)
     import os
     os.remove(tmp)
     return start_us, end_us, changed
+
+
+def tune_job(ts, next_batch, out, steps_done=None, lookahead=3, budget_s=120.0, steps=100, passes=1, comm=None, log=None, measure=None, sync=None):
+    """In-situ tuning as part of a RUNNING training job (run_training(..., tune=True) / RADNET_INSITU=1): the job's own steps are the
+    measurement.  next_batch() hands out the job's next batch (the samples train the model while the walk runs -- any launch shape
+    computes the same step); steps_done(n) is told how many steps each call consumed.  Bounded by `budget_s` seconds; the table is
+    written to `out` by rank 0 after every kept change and loaded by every rank when the walk ends.  Returns (us_before, us_after,
+    number of changes)."""
+    eng = ts.eng
+    window = []
+
+    def run(n):
+        for _ in range(n):
+            while len(window) < lookahead + 1:
+                window.append(next_batch())
+            batch = window.pop(0)
+            ts.step(batch, upcoming=window[:lookahead] if lookahead else None)
+        if steps_done is not None:
+            steps_done(n)
+
+    before, after, changed = tune(eng, run, ts.flush, out, passes=passes, steps=steps, budget_s=budget_s, n_prime=2 * getattr(ts, "NBUF", 1) + 2,
+                                  log=log or (lambda *a: None), comm=comm, measure=measure, sync=sync, only_new=True)
+    ts.flush()
+    return before, after, len(changed), window

@@ -224,9 +224,11 @@ class NativeTrainStep:
         return dict(self._last)
 
 
-def comm_init(eng, world, rank, dist=None, group=None):
-    """RCCL communicator on the engine's main context: rank 0 draws the id, torch.distributed (any backend -- the rendezvous
-    the job already has) carries its 128 bytes to the other ranks.  world == 1 needs no rendezvous."""
+def comm_init(eng, world, rank, dist=None, group=None, ctx=None):
+    """RCCL communicator on the engine's main context (or on `ctx`, a context of the engine's library): rank 0 draws the id,
+    torch.distributed (any backend -- the rendezvous the job already has) carries its 128 bytes to the other ranks.
+    world == 1 needs no rendezvous."""
+    ctx = ctx or eng.ctx
     ident = C.create_string_buffer(128)
     if rank == 0:
         rc = eng.lib.radnet_comm_unique_id(ident)
@@ -238,9 +240,10 @@ def comm_init(eng, world, rank, dist=None, group=None):
             t = t.to(eng.dev)
         dist.broadcast(t, src=0, group=group)
         ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
-    eng.ctx.check(eng.lib.radnet_comm_init(eng.ctx.h, world, rank, ident), "radnet_comm_init")
+    ctx.check(eng.lib.radnet_comm_init(ctx.h, world, rank, ident), "radnet_comm_init")
 
 
-def allreduce(eng, flat):
-    """In-place fp32 sum over the communicator, enqueued on the engine's current context stream."""
-    eng.ctx.check(eng.lib.radnet_allreduce_grads(eng.ctx.h, flat.data_ptr(), C.c_int64(flat.numel())), "radnet_allreduce_grads")
+def allreduce(eng, flat, ctx=None):
+    """In-place fp32 sum over the communicator of `ctx` (default: the engine's current context), enqueued on that context's stream."""
+    ctx = ctx or eng.ctx
+    ctx.check(eng.lib.radnet_allreduce_grads(ctx.h, flat.data_ptr(), C.c_int64(flat.numel())), "radnet_allreduce_grads")

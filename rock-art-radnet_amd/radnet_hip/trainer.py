@@ -54,6 +54,17 @@ def allreduce_grad_arena_start(flat, world, group=None):
     return None
 
 
+class _EventWork:
+    """Handle of an exchange issued on the native communicator's stream: wait() orders the CURRENT lane after it (an event wait,
+    no host synchronisation) -- the surface of torch.distributed's async work handles, which the deferred update uses."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class TrainStep:
     NBUF = 8        # buffer sets in rotation: this batch, up to four announced ones, whose head phase may still run; even,
                     # so that the sets alternate between the two prefetch lanes (and pairs of sets stay pairs)
@@ -79,6 +90,7 @@ class TrainStep:
             if dist.is_available() and dist.is_initialized():
                 self.group_head = dist.new_group(ranks=None if dist_group is None else dist.get_process_group_ranks(dist_group))
         self.defer_head_update = (world_size > 1) if defer_head_update is None else bool(defer_head_update)
+        self._init_native_comm()
         self._head_pending = None        # (work handle, images in the global batch) of the exchange in flight
         self._head_done = {}             # buffer set -> event: end of the head phase that last read its feature map
         self._head_last = None           # event: end of the last head phase enqueued on the head lane
@@ -117,8 +129,56 @@ class TrainStep:
         self._rpn_l = torch.zeros(self.NBUF, 64, 2, dtype=torch.float32, device=dev)     # per-image loss slots (logging)
         self._det_l = torch.zeros(self.NBUF, 64, 3, dtype=torch.float32, device=dev)
 
+    def _init_native_comm(self):
+        """Round 4: both gradient exchanges through the library's own RCCL binding (radnet_allreduce_grads: one ncclAllReduce on a
+        context's stream, ~5 us of host time) instead of torch.distributed (~45 us per call, its own streams and the event hops to
+        and from them).  AR#1 (RPN arena, 19 MB) is issued IN LINE on the main lane -- the stream its producer (RPN backward) and
+        consumer (Adam #1) run on.  AR#2 (head arena, 60 MB) gets a communicator on a stream of its own: one call after the head
+        backward, ordered by two events, finished (event wait) just before the next step's head forward -- the deferred update of
+        the torch path, without cutting the backward program into per-block buckets: the exchange has the whole RPN phase of the
+        next step to hide under.  torch.distributed stays for the rendezvous (128-byte ids) and the run's bookkeeping collectives.
+        Falls back to the torch path when the engine has no native library (recording engines of the CPU tests), the process
+        group is not RCCL (gloo rehearsals: several ranks on one GPU cannot share an RCCL communicator) or RADNET_NATIVE_COMM=0."""
+        self.native_comm = False
+        if not (self.world > 1 or FORCE_COLLECTIVES) or os.environ.get("RADNET_NATIVE_COMM", "1") != "1":
+            return
+        eng = self.eng
+        if not (hasattr(eng, "lib") and hasattr(eng, "ctx") and hasattr(eng.lib, "radnet_comm_init")) or not torch.cuda.is_available():
+            return
+        import torch.distributed as dist
+        ready = dist.is_available() and dist.is_initialized()
+        if self.world > 1 and (not ready or dist.get_backend(self.group) != "nccl"):
+            return
+        from . import lib as L
+        from . import native as N
+        try:
+            rank = dist.get_rank(self.group) if ready else 0
+            self._comm_stream = torch.cuda.Stream(device=eng.dev)
+            self._comm_ctx = L.Context(eng.dev.index, stream_handle=self._comm_stream.cuda_stream)
+            self._main_ctx = eng.ctx
+            N.comm_init(eng, self.world, rank, dist if ready else None, self.group, ctx=self._main_ctx)
+            N.comm_init(eng, self.world, rank, dist if ready else None, self.group, ctx=self._comm_ctx)
+            self.native_comm = True
+        except L.RadnetError as e:
+            import sys
+            sys.stderr.write("radnet: native RCCL exchange unavailable (%s); gradients travel through torch.distributed\n" % (e,))
+
     def _allreduce(self, arena):
+        if self.native_comm and arena is self.eng.rpn_arena:
+            from . import native as N
+            N.allreduce(self.eng, arena.g, ctx=self._main_ctx)      # in line on the main lane: after the RPN backward, before Adam #1
+            return
         allreduce_grad_arena(arena.g, self.world, self.group_head if arena is self.eng.head_arena else self.group)
+
+    def _native_head_exchange(self):
+        """AR#2 on the head communicator's stream, after everything enqueued so far on the current lane (the head backward)."""
+        from . import native as N
+        ready = self.eng.mark()
+        with torch.cuda.stream(self._comm_stream):
+            self.eng.after(ready)
+            N.allreduce(self.eng, self.eng.head_arena.g, ctx=self._comm_ctx)
+            done = self.eng.mark()
+        return _EventWork(done)
 
     def _finish_head_update(self):
         if self._head_pending is None:
@@ -501,7 +561,7 @@ class TrainStep:
         # final as soon as that block is differentiated -- their all-reduce starts then, beside the blocks still to come
         # (res5c 18 MB, res5b 18 MB, res5a 24 MB); only the last slice and the small tail are left at the end.
         slices = eng.head_exchange_slices() if hasattr(eng, "head_exchange_slices") else None
-        bucketed = self.defer_head_update and (self.world > 1 or FORCE_COLLECTIVES) and slices is not None
+        bucketed = self.defer_head_update and (self.world > 1 or FORCE_COLLECTIVES) and slices is not None and not self.native_comm
         works = []
 
         def exchange(lo, hi):
@@ -551,6 +611,12 @@ class TrainStep:
                             exchange(lo, hi)
                     exchange(eng.head_bias_off, eng.head_arena.n)      # biases + dense heads
                     self._head_pending = (works, ntot)
+                elif self.native_comm and self.defer_head_update:
+                    self._head_pending = ([self._native_head_exchange()], ntot)
+                elif self.native_comm:
+                    self._native_head_exchange().wait()
+                    eng.adam(eng.head_arena, grad_scale=1.0 / ntot)
+                    eng.refresh_head_shift()
                 elif self.defer_head_update:
                     self._head_pending = (allreduce_grad_arena_start(eng.head_arena.g, self.world, self.group_head), ntot)
                 else:

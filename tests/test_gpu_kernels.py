@@ -195,7 +195,7 @@ def test_conv_dgrad_wgrad(ctx, case):
 
 
 @pytest.mark.parametrize("case", [(3, 7, 7, 512, 512, 3, 1), (3, 7, 7, 2048, 512, 1, 0), (1, 19, 23, 128, 192, 3, 1), (2, 9, 11, 64, 96, 1, 0)])
-@pytest.mark.parametrize("shape", [(64, 64, 1), (64, 64, 3), (64, 64, -2), (128, 64, 1), None])
+@pytest.mark.parametrize("shape", [(64, 64, 1), (64, 64, 3), (64, 64, -2), (128, 64, 1), (32, 64, 1), (32, 64, 2), None])
 def test_conv_bwd_one_launch_equals_the_two_launches(ctx, case, shape):
     """radnet_conv_bwd (weight gradient + data gradient of a layer from one descriptor): with 64x64 tiles -- un-split, K-split
     with the in-launch reduction, XCD-ordered -- the two problems share ONE launch (conv_bwd_pair_kernel); with other shapes

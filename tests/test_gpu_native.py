@@ -188,3 +188,43 @@ def test_allreduce_grads_one_rank_communicator():
     assert np.array_equal(g.cpu().numpy(), want)
     eng.ctx.check(eng.lib.radnet_comm_destroy(eng.ctx.h), "comm_destroy")
     g.zero_()
+
+
+def test_pipelined_step_with_native_exchanges_equals_the_step_without_them():
+    """Round 4: the data-parallel schedule through the library's own RCCL binding (TrainStep.native_comm: AR#1 in line on the
+    main lane, AR#2 one call on the head communicator's stream, head update deferred to the next step's head forward),
+    rehearsed with 1-rank communicators -- every exchange an identity, so each loss, each weight and the random stream must
+    equal the plain pipelined step's bit for bit; any difference is a missing dependency between the lanes and the
+    communicator's stream."""
+    from radnet_hip import trainer as T
+    batches = [[sample(i)] for i in range(5)]
+    out = {}
+    for mode in ("plain", "native"):
+        C, P, eng = make()
+        T.FORCE_COLLECTIVES = mode == "native"
+        try:
+            ts = T.TrainStep(eng, world_size=1, defer_head_update=True if mode == "native" else None)
+            assert ts.native_comm == (mode == "native")
+            np.random.seed(64)
+            losses = []
+            for k, b in enumerate(batches):
+                ts.step(b, upcoming=batches[k + 1:k + 4])
+                losses.append(ts.losses())
+            ts.flush()
+            torch.cuda.synchronize()
+            out[mode] = (losses, eng.get_weights(), int(np.random.randint(0, 2 ** 31 - 1)))
+            if mode == "native":
+                import ctypes
+                calls, elems = ctypes.c_int64(), ctypes.c_int64()
+                eng.lib.radnet_comm_stats(ts._main_ctx.h, ctypes.byref(calls), ctypes.byref(elems))
+                assert calls.value == len(batches) and elems.value == len(batches) * eng.rpn_arena.n
+                eng.lib.radnet_comm_stats(ts._comm_ctx.h, ctypes.byref(calls), ctypes.byref(elems))
+                assert calls.value == len(batches) and elems.value == len(batches) * eng.head_arena.n
+        finally:
+            T.FORCE_COLLECTIVES = False
+    assert out["plain"][2] == out["native"][2]
+    for a, b in zip(out["plain"][0], out["native"][0]):
+        assert a == b, (a, b)
+    for name, d in out["plain"][1].items():
+        for k, v in d.items():
+            assert np.array_equal(v, out["native"][1][name][k]), (name, k)
