@@ -205,16 +205,42 @@ def layers_3x3_table(eng, bp, rp):
             t_dir = _time_graph_us(eng, [("conv", d)])
         except Exception:                                  # graphs switched off / capture failed: the stream-launch figures
             t_layer, t_dir = t_layer_stream, t_dir_stream
+        # ... and as it runs INSIDE the step's layer program: the frozen base forward (or the RPN forward) replayed as the step
+        # replays it, with and without the ops of this layer class (every op of the class removed: results of the stripped program
+        # are garbage, its timing is not) -- the difference per removed layer is what the layer costs where it runs, between its
+        # real neighbours, on buffers written once and read once.  The isolated loop above re-runs ONE layer on ONE set of
+        # buffers eight times in a row; for the stage-3 layers (32 MB of operands and results, the size of the L2s) it reads
+        # 5 us more than the step's own trace shows for the same three kernels (profiles/r04_kernel_sequence_one_lane.txt).
+        t_prog = None
+        try:
+            prog = list(bp["ops"]) if name != "rpn_conv1" else list(rp["fwd"])
+            cls = {"res3b_branch2b": ["res3%s_branch2b" % b for b in "abcd"], "res4b_branch2b": ["res4%s_branch2b" % b for b in "abcdef"],
+                   "rpn_conv1": ["rpn_conv1"]}[name]
+            us = {eng.convs[k].wino_u.data_ptr() for k in cls if eng.convs[k].wino_u is not None}
+            same = lambda op: op[0] == "wino" and op[1][7] in us and (op[1][1], op[1][2], op[1][3], op[1][4], op[1][5]) == (nb, hh, ww, cin, n)
+            stripped = [op for op in prog if not same(op)]
+            n_removed = len(prog) - len(stripped)
+            if n_removed and not any(k == "chain" for k, _ in prog):
+                t_full = min(_time_graph_us(eng, prog, reps=1, n=30), _time_graph_us(eng, prog, reps=1, n=30))
+                t_strip = min(_time_graph_us(eng, stripped, reps=1, n=30), _time_graph_us(eng, stripped, reps=1, n=30))
+                t_prog = (t_full - t_strip) / n_removed
+        except Exception:
+            t_prog = None
         algo = 2.0 * nb * hh * ww * n * 9 * cin
         execd = 2.0 * P * T * cin * n
+        t_frac = t_prog if (t_prog is not None and t_prog > 0) else t_layer
         rows.append({"layer": label, "M": nb * hh * ww, "N": n, "K": 9 * cin, "tiles": T, "winograd_form": "F(%dx%d,3x3)" % (form, form),
                      "winograd_us": {"input_transform": t_in, "gemm_batched": t_g, "gemms": P, "output_transform": t_out, "layer_back_to_back": t_layer,
-                                     "layer_stream_launches": t_layer_stream,
-                                     "how": "layer_back_to_back / direct_us: 8 passes in one hipGraph (as the step launches its programs), replayed; "
+                                     "layer_stream_launches": t_layer_stream, "layer_in_program": t_prog,
+                                     "how": "layer_in_program: (the layer program that holds the layer, replayed as a hipGraph) minus (the same program "
+                                            "without this layer class), per removed layer -- the layer's cost where the step runs it; "
+                                            "layer_back_to_back / direct_us: ONE layer 8 times in one hipGraph on one set of buffers; "
                                             "the three parts and layer_stream_launches: one host launch per kernel, 30 in a row"},
                      "direct_us": t_dir, "direct_stream_launches_us": t_dir_stream, "algorithmic_gflop": algo / 1e9, "winograd_executed_gflop": execd / 1e9,
                      "winograd_gemm_executed_tflops": execd / t_g / 1e6, "winograd_gemm_executed_frac": execd / t_g / 1e6 / PEAK_FP32_MFMA_TFLOPS,
-                     "winograd_layer_algorithmic_tflops": algo / t_layer / 1e6, "winograd_layer_algorithmic_frac": algo / t_layer / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                     "winograd_layer_algorithmic_tflops": algo / t_frac / 1e6, "winograd_layer_algorithmic_frac": algo / t_frac / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                     "winograd_layer_algorithmic_frac_basis": ("layer_in_program" if t_frac is t_prog else "layer_back_to_back"),
+                     "winograd_layer_algorithmic_frac_isolated_loop": algo / t_layer / 1e6 / PEAK_FP32_MFMA_TFLOPS,
                      "direct_tflops": algo / t_dir / 1e6, "direct_frac": algo / t_dir / 1e6 / PEAK_FP32_MFMA_TFLOPS})
     return rows
 
