@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-from tolerances import check  # noqa: E402  (max-norm + per-channel + RMS criteria, tests/tolerances.py)
+from tolerances import check, measure  # noqa: E402  (max-norm + per-channel + RMS criteria, tests/tolerances.py)
 
 
 def rel_err(a, b):
@@ -170,8 +170,11 @@ def test_cfg2_full_step_1000x600_vs_oracle():
         c = eng.convs[name]
         assert check(c.dweight.cpu().numpy(), gh_dev[name]["kernel"].reshape(-1, c.cout), 2e-3) < 2e-3, name
         assert check(c.dbias.cpu().numpy(), gh_dev[name]["bias"], 2e-3) < 2e-3, name
-        # against the oracle's own masks the max-norm and RMS criteria hold as well; only the per-channel one needs the mask alignment
-        assert check(c.dweight.cpu().numpy(), gh[name]["kernel"].reshape(-1, c.cout), 2e-3, floor=1e-2) < 2e-3, name
+        # against the oracle's OWN masks: max-norm and RMS only -- the per-channel criterion is the one that single flipped mask
+        # elements move (round 3 had loosened its floor to 1e-2 here; round 4's launch shapes put a channel at 3.4e-3 of a 2e-3
+        # bound even so, exactly the fragility the device-mask comparison above removes)
+        mx, _, rms = measure(c.dweight.cpu().numpy(), gh[name]["kernel"].reshape(-1, c.cout))
+        assert mx < 2e-3 and rms < 0.1 * 2e-3, (name, mx, rms)
         assert check(c.dbias.cpu().numpy(), gh[name]["bias"], 2e-3) < 2e-3, name
     dk, db = eng.dense_dw.cpu().numpy(), eng.dense_db.cpu().numpy()
     assert check(dk[:, :7], gh["dense_class_7"]["kernel"], 2e-3) < 2e-3 and check(dk[:, 7:31], gh["dense_regress_7"]["kernel"], 2e-3) < 2e-3
