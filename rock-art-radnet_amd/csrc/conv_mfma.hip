@@ -10,7 +10,9 @@
 //     consecutive channels); padding taps, ragged rows / columns and tiles past the end are an out-of-range offset
 //     that the hardware answers with zeros -- no branch anywhere in the K loop.
 //   * 4 wavefronts in a 2x2 arrangement (optionally 8: two grids halving every K tile); each wave owns a
-//     (BM/2)x(BN/2) block of the output as 32x32 MFMA tiles in accumulator registers for the whole K loop.
+//     (BM/2)x(BN/2) block of the output as 32x32 MFMA tiles in accumulator registers for the whole K loop.  32-row (32-column)
+//     tiles have one wave row (column): the waves left over split every K tile between them and are summed through LDS
+//     (round 4: M = 980 / 2 394 / 160-row problems fill the chip without K slices).
 //   * LDS double buffer.  The gathered operand (A; both operands in dgrad) is ROW-major [row][36]: written with one
 //     ds_write_b128 per 4-k chunk, read 4 k at a time with ds_read_b128 -- the k order inside a tile is free as long
 //     as both operands agree (mfma_tile_rows).  Forward weights stay k-major [k][BN+4] (conflict-free ds_read_b32).
