@@ -231,6 +231,12 @@ int radnet_det_loss(radnet_ctx* ctx, const float* p_cls, const float* p_regr, co
  * so the next step's backward can accumulate into it without a separate memset. */
 int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr,
                      float beta1, float beta2, float eps, float grad_scale, int32_t zero_grad);
+/* The same step with the folded epilogue shifts of the layers whose biases live in p[bias_off, bias_off + bias_len) refreshed in the
+ * same pass: shift[j] = scale[j] * p[bias_off + j] + t0[j] (the radnet_affine_vec call that otherwise follows the update of trainable
+ * convs with a frozen FixedBatchNormalization behind them, FixedBatchNormalization.py:59-85).  bias_off, bias_len multiples of 4. */
+int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1, float beta2,
+                            float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len, const float* scale,
+                            const float* t0, float* shift);
 
 /* ---- proposal decode + greedy NMS (rpn.py:68-172, 299-344, 380-455), fp64 ---------------------
  * pred: fused head output [rows*cols][ld_pred] (scores in [0,A), regression in [A,5A)).

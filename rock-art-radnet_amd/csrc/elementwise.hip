@@ -328,9 +328,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
 }
 
 // ---- keras.optimizers.Adam (Keras 2 update rule) over a flat arena ------------------------------------------
+// aff_*: optionally (radnet_adam_step_affine) the folded epilogue shifts of the convs whose biases live in [aff_off4, aff_off4 + aff_n4)
+// float4 chunks of the arena are refreshed from the just-updated biases in the same pass: shift = scale * bias + t0
+// (FixedBatchNormalization.py:59-85 folded; one launch fewer on the classifier lane per step).
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps,
-                                                   float gs, int zero_grad) {
+                                                   float gs, int zero_grad, long long aff_off4, long long aff_n4,
+                                                   const float* __restrict__ aff_scale, const float* __restrict__ aff_t0, float* __restrict__ aff_shift) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
@@ -347,6 +351,11 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
     if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aff_shift != nullptr && i >= aff_off4 && i < aff_off4 + aff_n4) {
+      const long long j = i - aff_off4;
+      const float4 a = reinterpret_cast<const float4*>(aff_scale)[j], c = reinterpret_cast<const float4*>(aff_t0)[j];
+      reinterpret_cast<float4*>(aff_shift)[j] = make_float4(a.x * pp.x + c.x, a.y * pp.y + c.y, a.z * pp.z + c.z, a.w * pp.w + c.w);
+    }
   }
 }
 
@@ -670,8 +679,24 @@ extern "C" int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, f
   // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (keras.optimizers.Adam.get_updates)
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
-                     beta1, beta2, eps, grad_scale, (int)zero_grad);
+                     beta1, beta2, eps, grad_scale, (int)zero_grad, 0ll, 0ll, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   RADNET_CHECK_LAUNCH(ctx, "adam");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
+                                       float beta2, float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len,
+                                       const float* scale, const float* t0, float* shift) {
+  if (!ctx || !p || !g || !m || !v || !scale || !t0 || !shift) return RADNET_ERR_ARG;
+  if ((n % 4) || (bias_off % 4) || (bias_len % 4) || bias_off < 0 || bias_len < 0 || bias_off + bias_len > n)
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_affine: arena length %lld, bias range [%lld, +%lld) must be multiples of 4 inside the arena", (long long)n,
+                (long long)bias_off, (long long)bias_len);
+  if (((uintptr_t)scale | (uintptr_t)t0 | (uintptr_t)shift) & 15) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_affine: scale / t0 / shift must be 16-byte aligned");
+  if (t < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: step counter starts at 1");
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
+                     beta1, beta2, eps, grad_scale, (int)zero_grad, (long long)(bias_off / 4), (long long)(bias_len / 4), scale, t0, shift);
+  RADNET_CHECK_LAUNCH(ctx, "adam_affine");
   return RADNET_OK;
 }
 

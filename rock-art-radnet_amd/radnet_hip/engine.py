@@ -317,7 +317,11 @@ class FasterRCNNEngine:
             self._refresh_winograd([n for n in self.INFERENCE_WINOGRAD_LAYERS if getattr(self.convs.get(n), "wino_u", None) is not None])
 
     def refresh_head_shift(self):
-        """shift = scale * bias + t0 for every stage-5 conv (FixedBatchNormalization.py:59-85 folded)."""
+        """shift = scale * bias + t0 for every stage-5 conv (FixedBatchNormalization.py:59-85 folded).  A no-op right after adam()
+        of the head arena, which refreshes the shifts in the same launch (radnet_adam_step_affine)."""
+        if getattr(self, "_head_shift_fresh", False):
+            self._head_shift_fresh = False
+            return
         bias = self.head_arena.p[self.head_bias_off:self.head_bias_off + self.head_bias_len]
         self.ctx.call("radnet_affine_vec", self.head_shift, self.head_scale, bias, self.head_t0, C.c_int64(self.head_bias_len))
 
@@ -977,8 +981,16 @@ class FasterRCNNEngine:
         """One Keras-2 Adam step over the arena.  zero_grad: the gradient arena is cleared in the same pass, so the
         next step's backward accumulates into zeros without a memset (arenas start zeroed, Arena.finalize)."""
         arena.t += 1
-        self.ctx.call("radnet_adam_step", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
-                      C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0)
+        fused = (arena is getattr(self, "head_arena", None) and getattr(self, "head_bias_len", 0) > 0 and self.head_bias_off % 4 == 0
+                 and self.head_bias_len % 4 == 0 and os.environ.get("RADNET_NO_ADAM_AFFINE", "0") != "1")
+        if fused:       # Adam #2 and the refresh of the classifier convs' folded shifts as one launch (round 4: one launch fewer on the head lane)
+            self.ctx.call("radnet_adam_step_affine", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
+                          C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0,
+                          C.c_int64(self.head_bias_off), C.c_int64(self.head_bias_len), self.head_scale, self.head_t0, self.head_shift)
+            self._head_shift_fresh = True
+        else:
+            self.ctx.call("radnet_adam_step", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
+                          C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0)
         if arena is self.rpn_arena:
             self._refresh_winograd(["rpn_conv1"])          # its forward runs on the transformed filter
         elif arena is getattr(self, "head_arena", None):
@@ -1296,6 +1308,11 @@ class FasterRCNNEngine:
         k = len(sel)
         o = group * (hp["R"] // hp.get("groups", 1))
         P["h_sel"][:k] = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32))
+        # the pack kernel reads the selection straight from the pinned (device-mapped) host buffer: no copy launch in front of it on the
+        # classifier lane (the buffer belongs to this buffer set: the host writes it again NBUF steps later at the earliest)
+        if self.KERNEL_COPIES and os.environ.get("RADNET_NO_PINNED_SEL", "0") != "1":
+            self.ctx.call("radnet_roi_batch_pack", P["h_sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"][o:], hp["y1"][o:], hp["y2"][o:])
+            return
         self._copy(P["sel"][:k], P["h_sel"][:k])
         self.ctx.call("radnet_roi_batch_pack", P["sel"], k, P["cls"], P["box"], P["t"], self.nc, int(self.bg), hp["rois"][o:], hp["y1"][o:], hp["y2"][o:])
 

@@ -181,6 +181,7 @@ def load_library():
         "radnet_rpn_loss": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
         "radnet_det_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "radnet_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32]),
+        "radnet_adam_step_affine": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, i32, i64, i64, vp, vp, vp]),
         "radnet_affine_vec": (C.c_int, [vp, vp, vp, vp, vp, i64]),
         "radnet_relu_mask": (C.c_int, [vp, vp, vp, i64]),
         "radnet_scatter_strided": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -196,11 +196,16 @@ def test_pipelined_step_with_native_exchanges_equals_the_step_without_them():
     rehearsed with 1-rank communicators -- every exchange an identity, so each loss, each weight and the random stream must
     equal the plain pipelined step's bit for bit; any difference is a missing dependency between the lanes and the
     communicator's stream."""
+    import os
+    import tempfile
     from radnet_hip import trainer as T
     batches = [[sample(i)] for i in range(5)]
     out = {}
-    for mode in ("plain", "native"):
+    table = os.path.join(tempfile.mkdtemp(), "shapes.txt")       # both engines on ONE table of launch shapes (another K-split count
+    for mode in ("plain", "native"):                             # re-associates the sums: bit equality holds for a given table)
         C, P, eng = make()
+        if os.path.exists(table):
+            eng.load_tuning(table)
         T.FORCE_COLLECTIVES = mode == "native"
         try:
             ts = T.TrainStep(eng, world_size=1, defer_head_update=True if mode == "native" else None)
@@ -213,6 +218,8 @@ def test_pipelined_step_with_native_exchanges_equals_the_step_without_them():
             ts.flush()
             torch.cuda.synchronize()
             out[mode] = (losses, eng.get_weights(), int(np.random.randint(0, 2 ** 31 - 1)))
+            if mode == "plain":
+                eng.save_tuning(table)
             if mode == "native":
                 import ctypes
                 calls, elems = ctypes.c_int64(), ctypes.c_int64()
