@@ -169,6 +169,11 @@ int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d);
  * each other's -- and as radnet_conv_wgrad followed by radnet_conv_dgrad otherwise (other launch shapes, d->dx == 0,
  * RADNET_NO_BWD_PAIR=1).  Same results as the two calls.  Timing class 4. */
 int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d);
+/* Two INDEPENDENT forward convolutions with the same output grid and reduction depth -- branch2a and the shortcut conv of a conv_block
+ * (resnet50.py:100,111: both read the block's input) -- as ONE launch where that measured faster than the two launches with their own
+ * launch shapes (decided once per pair of shapes, kept in the tuning table), as radnet_conv_fwd(d1), radnet_conv_fwd(d2) otherwise
+ * (different grids, 4-channel input, forced configs, autotuning off, RADNET_NO_FWD_PAIR=1).  Same results as the two calls. */
+int radnet_conv_fwd_pair(radnet_ctx* ctx, const radnet_conv_desc* d1, const radnet_conv_desc* d2);
 
 /* out[n] (+)= sum_m g[m][n] * gscale[n]   (bias gradients) */
 int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t n, int32_t ld, const float* gscale,
@@ -335,6 +340,7 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  * a hipGraph.  Argument slots per kind (i = integers, p = device pointers):
  *   CONV_FWD / CONV_DGRAD / CONV_WGRAD   conv
  *   CONV_BWD     conv (radnet_conv_bwd: weight gradient + data gradient of the layer);  NOP: skipped
+ *   CONV_FWD_PAIR conv = first convolution, the NEXT op's conv = second (its kind is NOP): radnet_conv_fwd_pair
  *   MAXPOOL      p: x, y                     i: nb, h, w, c, k, s
  *   COLSUM       p: g, gscale|0, out         i: m, n, ld, accumulate
  *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy, form   (radnet_winograd_input + 16
@@ -349,7 +355,8 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
 enum {
   RADNET_OP_CONV_FWD = 1, RADNET_OP_CONV_DGRAD = 2, RADNET_OP_CONV_WGRAD = 3, RADNET_OP_MAXPOOL = 4, RADNET_OP_COLSUM = 5,
   RADNET_OP_WINO = 6, RADNET_OP_WINO_REUSE = 7, RADNET_OP_WINO_WGRAD = 8, RADNET_OP_SCATTER = 9, RADNET_OP_FILL0 = 10,
-  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_CHAIN = 14, RADNET_OP_NOP = 0
+  RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_CHAIN = 14, RADNET_OP_CONV_FWD_PAIR = 15,
+  RADNET_OP_NOP = 0
 };
 typedef struct radnet_op {
   int32_t kind;

@@ -902,6 +902,23 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
   conv_igemm_body<BM, BN, BMODE, SMALLC, WAVES>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
+// Two INDEPENDENT forward problems as one launch (round 4: branch2a and the shortcut conv of a conv_block read the same input,
+// resnet50.py:100,111): workgroups [0, n1) run the first, [n1, n1 + n2) the second -- one launch floor (~4 us + a lockstep
+// prologue / epilogue) instead of two, and the narrow branch2a grid (N = 128 .. 512) no longer has the chip to itself.  Plain grids,
+// one tile shape for both.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) conv_fwd_pair_kernel(GemmArgs g1, GemmArgs g2, unsigned n1, unsigned gx1, unsigned gx2) {
+  __shared__ __attribute__((aligned(16))) float lds[igemm_lds_floats<BM, BN, 0>()];
+  const unsigned b = blockIdx.x;
+  if (b < n1) {
+    const unsigned by = b / gx1;
+    conv_igemm_body<BM, BN, 0, false, 4>(g1, lds, b - by * gx1, by, 0u, gx1);
+  } else {
+    const unsigned c = b - n1, by = c / gx2;
+    conv_igemm_body<BM, BN, 0, false, 4>(g2, lds, c - by * gx2, by, 0u, gx2);
+  }
+}
+
 // ---- wgrad kernel -----------------------------------------------------------------------------------
 // dW[k][n] (+)= sum_m im2col(x)[m][k] * (dy[m][n] * gscale[n]).  Output tile BMK (k) x BN (n); the
 // reduction runs over output pixels m in steps of 32, optionally split across blockIdx.z (atomics).
@@ -1456,7 +1473,8 @@ struct PairPause {
   ~PairPause() { ctx->pair_capture = saved; }
 };
 
-int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
+// checks + derived fields of a forward / data-gradient problem (descriptor extents, division constants)
+int prepare_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   if (g.M >= (1 << 20) || g.OHOW >= (1 << 20)) RADNET_FAIL(ctx, RADNET_ERR_UNSUPPORTED, "conv: M=%d exceeds 2^20 rows", g.M);
   if ((g.ldw & 3) || (g.N & 3)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv: N=%d and ldw=%d must be multiples of 4", g.N, g.ldw);
@@ -1486,6 +1504,14 @@ int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
 #ifdef RADNET_DIAG_STAMPS
   if (getenv("RADNET_DIAG_NOMEM")) g.x_bytes = g.w_bytes = 0;   // every operand load out of range: returns 0 without touching memory
 #endif
+  return RADNET_OK;
+}
+
+int run_igemm(radnet_ctx* ctx, GemmArgs& g, int bmode, bool smallc, int cls) {
+  {
+    const int rcp = prepare_igemm(ctx, g, bmode, smallc);
+    if (rcp != RADNET_OK) return rcp;
+  }
   const int nk = radnet_cdiv(g.K, BK);
   // TileChoice.splits = number of equal work chunks the iteration space is cut into (0/1 = one workgroup per tile)
   auto launch = [&](const TileChoice& t) -> int {
@@ -1908,10 +1934,9 @@ extern "C" int radnet_diag_set_stamps(radnet_ctx* ctx, unsigned long long* dev_b
 }
 #endif
 
-extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
-  if (!ctx || !d) return RADNET_ERR_ARG;
+static int fwd_args(radnet_ctx* ctx, const radnet_conv_desc* d, GemmArgs& g) {
   if (!d->x || !d->w || !d->y) RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_fwd: null tensor");
-  GemmArgs g{};
+  g = GemmArgs{};
   g.x = d->x; g.w = d->w; g.y = d->y;
   g.scale = d->scale; g.shift = d->shift; g.addend = d->addend; g.mask = nullptr; g.in_scale = nullptr;
   g.H = d->h; g.W = d->w_; g.C = d->c; g.OH = d->oh; g.OW = d->ow;
@@ -1923,7 +1948,82 @@ extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   // geometry sanity: every output pixel's window must be addressable by the gather's bounds checks
   if ((d->oh - 1) * d->stride - d->pad_t >= d->h || (d->ow - 1) * d->stride - d->pad_l >= d->w_)
     RADNET_FAIL(ctx, RADNET_ERR_ARG, "conv_fwd: output %dx%d inconsistent with input %dx%d", d->oh, d->ow, d->h, d->w_);
-  return run_igemm(ctx, g, 0, d->c == 4, 0);
+  return RADNET_OK;
+}
+
+extern "C" int radnet_conv_fwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
+  if (!ctx || !d) return RADNET_ERR_ARG;
+  GemmArgs g;
+  const int rc = fwd_args(ctx, d, g);
+  return rc != RADNET_OK ? rc : run_igemm(ctx, g, 0, d->c == 4, 0);
+}
+
+// Two independent forward convolutions (same output grid and reduction depth: branch2a and the shortcut conv of a conv_block) as ONE
+// launch where that measured faster than the two launches with their own tuned shapes (conv_fwd_pair_kernel; decided once per pair
+// of shapes, kind 32 in the tuning table: slices 1 = paired with that tile, 2 = two launches); the two launches otherwise.
+extern "C" int radnet_conv_fwd_pair(radnet_ctx* ctx, const radnet_conv_desc* d1, const radnet_conv_desc* d2) {
+  if (!ctx || !d1 || !d2) return RADNET_ERR_ARG;
+  GemmArgs g1, g2;
+  int rc = fwd_args(ctx, d1, g1);
+  if (rc == RADNET_OK) rc = fwd_args(ctx, d2, g2);
+  if (rc != RADNET_OK) return rc;
+  auto separate = [&]() -> int {
+    GemmArgs a = g1, b = g2;
+    int r = run_igemm(ctx, a, 0, d1->c == 4, 0);
+    return r != RADNET_OK ? r : run_igemm(ctx, b, 0, d2->c == 4, 0);
+  };
+  static const bool disabled = getenv("RADNET_NO_FWD_PAIR") != nullptr;
+  const bool same_grid = g1.M == g2.M && g1.K == g2.K && g1.C == g2.C && g1.npos == g2.npos && g1.stride == g2.stride;
+  if (disabled || !same_grid || d1->c == 4 || (g1.C % BK) != 0 || ctx->force_a > 0 || ctx->pair_capture != nullptr || !ctx->autotune) return separate();
+  rc = prepare_igemm(ctx, g1, 0, false);
+  if (rc == RADNET_OK) rc = prepare_igemm(ctx, g2, 0, false);
+  if (rc != RADNET_OK) return rc;
+  g1.units = g2.units = nullptr; g1.partial = g2.partial = nullptr; g1.counters = g2.counters = nullptr;
+  g1.batch = g2.batch = 0; g1.xcd_batch = g2.xcd_batch = 0; g1.zper = g2.zper = 0;
+  auto paired = [&](int bm, int bn) -> int {
+    const unsigned gx1 = (unsigned)radnet_cdiv(g1.M, bm), gx2 = (unsigned)radnet_cdiv(g2.M, bm);
+    const unsigned n1 = gx1 * (unsigned)radnet_cdiv(g1.N, bn), n2 = gx2 * (unsigned)radnet_cdiv(g2.N, bn);
+    dim3 grid(n1 + n2), block(256);
+    if (bm == 64 && bn == 64) RADNET_LAUNCH((conv_fwd_pair_kernel<64, 64>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g1, g2, n1, gx1, gx2);
+    else if (bm == 32 && bn == 64) RADNET_LAUNCH((conv_fwd_pair_kernel<32, 64>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g1, g2, n1, gx1, gx2);
+    else if (bm == 32 && bn == 32) RADNET_LAUNCH((conv_fwd_pair_kernel<32, 32>), grid, block, 0, ctx->stream, ctx->arm0, ctx->arm1, g1, g2, n1, gx1, gx2);
+    else return RADNET_ERR_UNSUPPORTED;
+    RADNET_CHECK_LAUNCH(ctx, "conv_fwd_pair");
+    return RADNET_OK;
+  };
+  const radnet_shape_key key{32, g1.M, g1.N * 65536 + g2.N, g1.K, g1.C, g1.npos, g1.stride};
+  auto it = ctx->tuned->find(key);
+  if (it == ctx->tuned->end()) {
+    // first use of this pair of shapes: the two launches (which measures each of them, if new) against the pair on every tile it has
+    rc = separate();
+    if (rc != RADNET_OK) return rc;
+    float best = 0.f;
+    rc = radnet_time_launches(ctx, separate, 12, &best);
+    if (rc != RADNET_OK) return rc;
+    radnet_tuned choice{64, 64, 2, best, 4};
+    const int tiles[3][2] = {{64, 64}, {32, 64}, {32, 32}};
+    for (const auto& t : tiles) {
+      float m1 = 0.f, m2 = 0.f;
+      rc = radnet_time_launches(ctx, [&]() { return paired(t[0], t[1]); }, 12, &m1);
+      if (rc == RADNET_OK) rc = radnet_time_launches(ctx, [&]() { return paired(t[0], t[1]); }, 12, &m2);
+      if (rc != RADNET_OK) return rc;
+      const float ms = std::min(m1, m2);
+      if (ms < choice.ms) choice = radnet_tuned{t[0], t[1], 1, ms, 4};
+    }
+    (*ctx->tuned)[key] = choice;
+    if (getenv("RADNET_TUNE_LOG"))
+      fprintf(stderr, "[radnet tune] fwd pair M=%d N=%d+%d K=%d -> %s (%.1f us; the two launches %.1f us)\n", g1.M, g1.N, g2.N, g1.K,
+              choice.splits == 1 ? (choice.a == 64 ? "one launch, 64x64" : choice.b == 64 ? "one launch, 32x64" : "one launch, 32x32") : "two launches",
+              choice.ms * 1e3, best * 1e3);
+    it = ctx->tuned->find(key);
+  }
+  if (it->second.splits != 1) return separate();
+  radnet_timing_arm(ctx);
+  rc = paired(it->second.a, it->second.b);
+  if (rc == RADNET_ERR_UNSUPPORTED) return separate();
+  if (rc != RADNET_OK) return rc;
+  radnet_timing_end_armed(ctx, 0, 2.0 * g1.M * (double)(g1.N + g2.N) * g1.K);
+  return RADNET_OK;
 }
 
 extern "C" int radnet_gemm_batched(radnet_ctx* ctx, const float* a, const float* b, float* y, int32_t batch, int32_t m, int32_t n, int32_t k) {

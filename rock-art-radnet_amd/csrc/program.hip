@@ -81,6 +81,10 @@ extern "C" int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t
       case RADNET_OP_CONV_DGRAD: rc = radnet_conv_dgrad(ctx, &o.conv); break;
       case RADNET_OP_CONV_WGRAD: rc = radnet_conv_wgrad(ctx, &o.conv); break;
       case RADNET_OP_CONV_BWD: rc = radnet_conv_bwd(ctx, &o.conv); break;
+      case RADNET_OP_CONV_FWD_PAIR:
+        if (k + 1 >= n_ops || ops[k + 1].kind != RADNET_OP_NOP) RADNET_FAIL(ctx, RADNET_ERR_ARG, "program: CONV_FWD_PAIR at %d without its second descriptor (a NOP slot)", k);
+        rc = radnet_conv_fwd_pair(ctx, &o.conv, &ops[k + 1].conv);
+        break;
       case RADNET_OP_NOP: rc = RADNET_OK; break;
       case RADNET_OP_MAXPOOL:
         rc = radnet_maxpool_fwd(ctx, (const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5]);

@@ -165,6 +165,8 @@ class FasterRCNNEngine:
         self.use_winograd = os.environ.get("RADNET_NO_WINOGRAD", "0") != "1"
         # frozen base forward (stages 2-4) as one persistent launch of `chain_wgs` workgroups (0: two per CU); DESIGN.md 4
         self.use_chain = os.environ.get("RADNET_CHAIN", "0") == "1"
+        # branch2a + shortcut conv of a conv_block as one call (radnet_conv_fwd_pair decides per shape pair whether one launch is faster)
+        self.fwd_pair = os.environ.get("RADNET_NO_FWD_PAIR", "0") != "1" and not self.use_chain
         # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
         # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
@@ -498,14 +500,20 @@ class FasterRCNNEngine:
                 ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
                 oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
                 a = buf(nb, oh, ow, f1)
-                d, _, _ = self._desc(ca, cur, nb, h, w, a); ops.append(("conv", d))
-                bb = buf(nb, oh, ow, f2)
-                op, _ = self._fwd_op(cb, a, nb, oh, ow, bb, keep); ops.append(op)
+                da, _, _ = self._desc(ca, cur, nb, h, w, a)
                 if first:
                     sc = buf(nb, oh, ow, f3)
-                    d, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False); ops.append(("conv", d))
+                    ds, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False)
                 else:
                     sc = cur
+                if first and self.fwd_pair:        # branch2a and the shortcut read the same input: one launch where it measures faster
+                    ops += [("conv_pair_first", da), ("conv_pair_second", ds)]
+                else:
+                    ops.append(("conv", da))
+                bb = buf(nb, oh, ow, f2)
+                op, _ = self._fwd_op(cb, a, nb, oh, ow, bb, keep); ops.append(op)
+                if first and not self.fwd_pair:
+                    ops.append(("conv", ds))
                 out = buf(nb, oh, ow, f3)
                 d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
                 cur, h, w = out, oh, ow
@@ -694,7 +702,13 @@ class FasterRCNNEngine:
                 paired = False
                 o.kind = L.OP_NOP
                 continue
-            if kind in ("conv", "dgrad", "wgrad"):
+            if kind == "conv_pair_first":           # branch2a + shortcut conv of a conv_block: one call (radnet_conv_fwd_pair), the second
+                o.kind = L.OP_CONV_FWD_PAIR         # descriptor rides in the following NOP slot
+                o.conv = p
+            elif kind == "conv_pair_second":
+                o.kind = L.OP_NOP
+                o.conv = p
+            elif kind in ("conv", "dgrad", "wgrad"):
                 o.kind = {"conv": L.OP_CONV_FWD, "dgrad": L.OP_CONV_DGRAD, "wgrad": L.OP_CONV_WGRAD}[kind]
                 o.conv = p
                 # weight gradient and data gradient of one layer (same descriptor) -> one launch (radnet_conv_bwd)
@@ -1037,15 +1051,21 @@ class FasterRCNNEngine:
             first = bl == "a"
             ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
             oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
-            a = buf(R, oh, ow, f1); da, _, _ = self._desc(ca, cur, R, h, w, a); fwd.append(("conv", da))
+            a = buf(R, oh, ow, f1); da, _, _ = self._desc(ca, cur, R, h, w, a)
+            ds = None
+            if first:
+                sc = buf(R, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, R, h, w, sc, relu=False)
+            else:
+                sc = cur
+            if first and self.fwd_pair:            # branch2a and the shortcut read the same input: one launch where it measures faster
+                fwd += [("conv_pair_first", da), ("conv_pair_second", ds)]
+            else:
+                fwd.append(("conv", da))
             bb = buf(R, oh, ow, f2)
             op_b, db = self._fwd_op(cb, a, R, oh, ow, bb, keep, relu=True, inference=not training)
             fwd.append(op_b)
-            ds = None
-            if first:
-                sc = buf(R, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, R, h, w, sc, relu=False); fwd.append(("conv", ds))
-            else:
-                sc = cur
+            if first and not self.fwd_pair:
+                fwd.append(("conv", ds))
             out = buf(R, oh, ow, f3); dc, _, _ = self._desc(cc, bb, R, oh, ow, out, relu=True, addend=sc); fwd.append(("conv", dc))
             blocks.append(dict(first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, names=(b + "2a", b + "2b", b + "2c", b + "1")))
             cur, h, w = out, oh, ow

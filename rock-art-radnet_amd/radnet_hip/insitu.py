@@ -51,6 +51,9 @@ def neighbours(key, cur):
     kind, m, n, k, c, npos, stride = key
     a, b, s, _, w = cur
     out = []
+    if kind == 32:      # radnet_conv_fwd_pair's decision for a pair of shapes: one launch on tile a x b (slices 1) or the two launches (slices 2)
+        cands = [(64, 64, 1, 4), (32, 64, 1, 4), (32, 32, 1, 4), (a, b, 2, 4)]
+        return [o for o in cands if o != (a, b, s, w) and not (s == 2 and o[2] == 2)]
     wgrad = (kind & 7) in (2, 3)
     batched = kind >= 8
     if wgrad:
@@ -247,6 +250,9 @@ def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, 
                     raise
                 log("  %-44s %s -> %s : %.1f / %.1f us vs %.1f %s" % (key, tuple(cur[:3] + [cur[4]]), cand, t1, t2, best, "KEPT" if ok else ""))
                 if ok:
+                    if key[0] in (8, 18):      # the 36 / 16 GEMMs of a Winograd 3x3 layer: the north-star's per-layer table times them ALONE
+                        log("    note: %s is a Winograd layer's batched GEMM; this change was accepted for the step's throughput and may cost "
+                            "the layer's isolated figure -- re-read roofline.layers_3x3 of the next bench line" % (key,))
                     tab = trial
                     cur = list(tab[key])
                     best = max(t1, t2)

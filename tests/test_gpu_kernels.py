@@ -742,3 +742,36 @@ def test_copy_bytes_between_pinned_host_and_device(ctx):
         assert np.array_equal(dev2.cpu().numpy(), src.numpy()[off:]), (n, off)
         assert int(dev_buf[off + n:].sum()) == 0 and int(back[:off].sum()) == 0          # nothing written outside the range
     assert ctx.lib.radnet_copy_bytes(ctx.h, None, None, C.c_uint64(0)) == 0             # empty copy: no launch, no error
+
+
+@pytest.mark.parametrize("case", [(3, 14, 14, 1024, 512, 2048, 2), (1, 21, 30, 256, 128, 512, 2), (2, 9, 11, 64, 64, 96, 1)])
+def test_conv_fwd_pair_equals_the_two_convolutions(ctx, case):
+    """radnet_conv_fwd_pair (round 4: branch2a + shortcut conv of a conv_block, same input, as ONE launch where that measures faster):
+    the first call decides (measures the two launches against the paired launch on every tile it has), later calls use the
+    decision; both outputs against the oracle either way, ragged N and M edges included."""
+    from radnet_hip import lib as L
+    from oracle import dense
+    nb, h, w, cin, n1, n2, stride = case
+    rs = np.random.RandomState(sum(case) + 11)
+    x = np.maximum(rs.standard_normal((nb, h, w, cin)), 0).astype(np.float32)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    outs = []
+    descs = []
+    keep = [dev(x)]
+    for n, relu in ((n1, True), (n2, False)):
+        wt = (rs.standard_normal((1, 1, cin, n)) / np.sqrt(cin)).astype(np.float32)
+        b = rs.standard_normal(n).astype(np.float32)
+        sc = rs.uniform(0.5, 1.5, n).astype(np.float32)
+        ref = dense.conv2d(x.astype(np.float64), wt.astype(np.float64), None, stride, (0,) * 4) * sc + b
+        ref = np.maximum(ref, 0) if relu else ref
+        y = torch.full((nb, oh, ow, n), float("nan"), dtype=torch.float32, device="cuda")
+        wd, sd, bd = dev(wt.reshape(-1, n)), dev(sc), dev(b)
+        keep += [wd, sd, bd]
+        descs.append(conv_desc(L, keep[0], wd, y, nb, h, w, cin, oh, ow, 1, stride, 0, n, n, sd, bd, None, 1 if relu else 0))
+        outs.append((y, ref))
+    for rep in range(3):
+        for y, _ in outs:
+            y.fill_(float("nan"))
+        ctx.check(ctx.lib.radnet_conv_fwd_pair(ctx.h, C.byref(descs[0]), C.byref(descs[1])), "conv_fwd_pair")
+        for y, ref in outs:
+            close(y.cpu().numpy(), ref)
