@@ -166,7 +166,7 @@ class FasterRCNNEngine:
         # frozen base forward (stages 2-4) as one persistent launch of `chain_wgs` workgroups (0: two per CU); DESIGN.md 4
         self.use_chain = os.environ.get("RADNET_CHAIN", "0") == "1"
         # branch2a + shortcut conv of a conv_block as one call (radnet_conv_fwd_pair decides per shape pair whether one launch is faster)
-        self.fwd_pair = os.environ.get("RADNET_NO_FWD_PAIR", "0") != "1" and not self.use_chain
+        self.fwd_pair = os.environ.get("RADNET_NO_FWD_PAIR", "0") != "1"      # (a base plan built for the chain kernel keeps the single convs)
         # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
         # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
@@ -506,13 +506,14 @@ class FasterRCNNEngine:
                     ds, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False)
                 else:
                     sc = cur
-                if first and self.fwd_pair:        # branch2a and the shortcut read the same input: one launch where it measures faster
+                pair = first and self.fwd_pair and not self.use_chain
+                if pair:                           # branch2a and the shortcut read the same input: one launch where it measures faster
                     ops += [("conv_pair_first", da), ("conv_pair_second", ds)]
                 else:
                     ops.append(("conv", da))
                 bb = buf(nb, oh, ow, f2)
                 op, _ = self._fwd_op(cb, a, nb, oh, ow, bb, keep); ops.append(op)
-                if first and not self.fwd_pair:
+                if first and not pair:
                     ops.append(("conv", ds))
                 out = buf(nb, oh, ow, f3)
                 d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
