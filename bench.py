@@ -123,15 +123,18 @@ def _time_graph_us(eng, ops, reps=8, n=20):
 
 def committed_pmc_traffic():
     """HBM bytes per launch of the dominant GEMM kernel from the committed PMC passes of this same command
-    (profiles/r03_pmc_summary_insitu_tables.txt, else the earlier ones: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
-    tools/collect_profiles.sh, FETCH_SIZE doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  A profiler
+    (profiles/r04_pmc_summary.txt, else the earlier rounds': FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs by
+    tools/collect_profiles_r04.sh, FETCH_SIZE doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  A profiler
     cannot run inside this process: the figure is the last committed measurement, or None when the file is not there."""
     import re
-    for name in ("r03_pmc_summary_insitu_tables.txt", "r03_pmc_summary.txt", "r02_pmc_summary.txt"):
+    # the dominant GEMM kernel by time per step: round 4 conv_igemm_kernel<32, 64, 0, false, 4> (17 launches, 485 us of 2 545 on one lane,
+    # profiles/r04_trace_summary_one_lane.txt); earlier rounds' summaries know the 64x64 class only
+    for name, kern in (("r04_pmc_summary.txt", r"conv_igemm_kernel<32, 64, 0, false, 4>"), ("r03_pmc_summary_insitu_tables.txt", r"conv_igemm_kernel<64, 64, 0, false, 4>"),
+                       ("r03_pmc_summary.txt", r"conv_igemm_kernel<64, 64, 0, false, 4>"), ("r02_pmc_summary.txt", r"conv_igemm_kernel<64, 64, 0, false, 4>")):
         path = os.path.join(ROOT, "profiles", name)
         try:
             for line in open(path):
-                m = re.search(r"^\s*(conv_igemm_kernel<64, 64, 0, false, 4>)\s+per launch: FETCH_SIZE\s+([0-9.]+) MB \(x2 =\s+([0-9.]+) MB\)\s+WRITE_SIZE\s+([0-9.]+) MB", line)
+                m = re.search(r"^\s*(" + re.escape(kern) + r")\s+per launch: FETCH_SIZE\s+([0-9.]+) MB \(x2 =\s+([0-9.]+) MB\)\s+WRITE_SIZE\s+([0-9.]+) MB", line)
                 if m:
                     return {"kernel": m.group(1), "bytes": (float(m.group(3)) + float(m.group(4))) * 1e6,
                             "fetch_bytes_corrected": float(m.group(3)) * 1e6, "write_bytes": float(m.group(4)) * 1e6,
