@@ -174,6 +174,14 @@ int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d);
  * launch shapes (decided once per pair of shapes, kept in the tuning table), as radnet_conv_fwd(d1), radnet_conv_fwd(d2) otherwise
  * (different grids, 4-channel input, forced configs, autotuning off, RADNET_NO_FWD_PAIR=1).  Same results as the two calls. */
 int radnet_conv_fwd_pair(radnet_ctx* ctx, const radnet_conv_desc* d1, const radnet_conv_desc* d2);
+/* The back of a bottleneck block (resnet50.py:53-71, 104-128) as ONE launch: db = its 3x3 convolution (stride 1, 'same', 64 output
+ * channels, ReLU), dc = its 1x1 expand on db's output (dc->x == db->y; + shortcut dc->addend, ReLU), da = the NEXT block's 1x1 reduce on
+ * dc's output (da->x == dc->y, 64 output channels, ReLU) or 0.  A workgroup that holds [rows x 64] of the 3x3's output holds all of that
+ * layer's channels for its rows and goes on with the pointwise convolutions for the same rows through LDS: db->y is NOT written
+ * (frozen layers only -- nothing can be differentiated through the block afterwards), dc->y once, da->x is not read back.  Used where it
+ * measured faster than the separate launches (decided once per shape, kept in the tuning table); radnet_conv_fwd(db), (dc), (da) -- which
+ * do write db->y -- for every other geometry, forced configs, autotuning off, RADNET_NO_BNECK_FUSE=1. */
+int radnet_conv_bottleneck(radnet_ctx* ctx, const radnet_conv_desc* db, const radnet_conv_desc* dc, const radnet_conv_desc* da);
 
 /* out[n] (+)= sum_m g[m][n] * gscale[n]   (bias gradients) */
 int radnet_colsum(radnet_ctx* ctx, const float* g, int32_t m, int32_t n, int32_t ld, const float* gscale,
@@ -341,6 +349,7 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  *   CONV_FWD / CONV_DGRAD / CONV_WGRAD   conv
  *   CONV_BWD     conv (radnet_conv_bwd: weight gradient + data gradient of the layer);  NOP: skipped
  *   CONV_FWD_PAIR conv = first convolution, the NEXT op's conv = second (its kind is NOP): radnet_conv_fwd_pair
+ *   CONV_BNECK   conv = db, the next op's conv = dc, i[0] = 1: the op after that holds da (both NOP slots): radnet_conv_bottleneck
  *   MAXPOOL      p: x, y                     i: nb, h, w, c, k, s
  *   COLSUM       p: g, gscale|0, out         i: m, n, ld, accumulate
  *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy, form   (radnet_winograd_input + 16
@@ -356,6 +365,7 @@ enum {
   RADNET_OP_CONV_FWD = 1, RADNET_OP_CONV_DGRAD = 2, RADNET_OP_CONV_WGRAD = 3, RADNET_OP_MAXPOOL = 4, RADNET_OP_COLSUM = 5,
   RADNET_OP_WINO = 6, RADNET_OP_WINO_REUSE = 7, RADNET_OP_WINO_WGRAD = 8, RADNET_OP_SCATTER = 9, RADNET_OP_FILL0 = 10,
   RADNET_OP_RELU_MASK = 11, RADNET_OP_ROI_BWD = 12, RADNET_OP_CONV_BWD = 13, RADNET_OP_CHAIN = 14, RADNET_OP_CONV_FWD_PAIR = 15,
+  RADNET_OP_CONV_BNECK = 16,
   RADNET_OP_NOP = 0
 };
 typedef struct radnet_op {

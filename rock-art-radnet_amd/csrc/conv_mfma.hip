@@ -277,6 +277,126 @@ constexpr int igemm_persist_scratch_floats() {
   return (KH - 1) * BM * BN;
 }
 
+// ---- fused bottleneck tail (round 4) ----------------------------------------------------------------------------------
+// A ResNet identity / conv block is 1x1 reduce -> 3x3 -> 1x1 expand (+ shortcut, ReLU) (resnet50.py:41-71, 74-128).  In stage 2
+// (C = 64 / 256 on the 150x250 map) the two pointwise convs are memory-shaped launches: 1.2 GF each for 48 MB moved, 50-66 TFLOP/s,
+// and three launches per block.  Cut the chain in front of the 3x3 instead of behind it and nothing needs a halo: a workgroup that
+// holds a [BM rows x 64] tile of the 3x3 output holds ALL of that layer's channels for its rows, so it can go on, for the same rows,
+//   y[rows][N2]  = relu(t2 . W2 * sc2 + sh2 + shortcut[rows][N2])          (branch2c, Add, Activation)
+//   t'[rows][64] = relu(y . W3 * sc3 + sh3)                                 (the NEXT block's branch2a), optional
+// with t2 and y passed between the three GEMMs through LDS; t2 is never written to memory, y once, and the next block's 1x1 input
+// is not read back.  The tail GEMMs run on the same 2x2 (2x1) wave grid as the 3x3: A fragments from LDS in the K loop's own row-major
+// layout (mfma_tile_rows), B fragments straight from the 64 KB weight matrices in L2 (every workgroup reads the same ones; one dword per
+// lane and MFMA step, no staging, no barrier).  Frozen layers only: the block's intermediate activations do not exist afterwards.
+struct TailArgs {
+  const float* w2; const float* sc2; const float* sh2; const float* add; float* y;     // expand: [64][ldw2], columns N2 (multiple of 64)
+  const float* w3; const float* sc3; const float* sh3; float* t;                        // next reduce: [N2][ldw3] -> 64 columns, or null
+  int N2, ldw2, ldy2, ld_add2, ldw3, ldt;
+  unsigned w2_bytes, w3_bytes, y_bytes, add_bytes, t_bytes;
+};
+template <int BM>
+constexpr int bneck_lds_floats() { return 4 * BM * (BK + 4); }     // the 3x3 tile and one 64-column chunk of y, each as two 32-deep A tiles
+
+// one 64-deep GEMM step of the tail: acc += A[rows][64] (LDS, two row-major 32-deep tiles) . B (fragments in registers)
+// (ONE accumulator: the tail's registers decide how many workgroups share a CU, and those other waves fill the MFMA pipe between two
+// dependent steps of this one)
+__device__ __forceinline__ void bneck_mfma64(const float* sA, int buf_floats, int a_off, const float (&bw)[32], f32x16& acc) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 af = *reinterpret_cast<const float4*>(sA + half * buf_floats + a_off + 8 * q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int s = 16 * half + 4 * q + c;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_comp(af, c), bw[s], acc, 0, 0, 0);
+      }
+    }
+}
+// B fragments of such a step: lane (hi, l31) multiplies k = 32 half + 8 q + 4 hi + c in step (half, q, c) -- the order mfma_tile_rows uses
+__device__ __forceinline__ void bneck_load_b(__amdgpu_buffer_rsrc_t rw, unsigned voff, unsigned row0, unsigned ld4, bool live, float (&bw)[32]) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const unsigned k = 32u * (s >> 4) + 8u * ((s & 15) >> 2) + (s & 3);
+    bw[s] = buf_load1s(rw, voff, live ? (row0 + k) * ld4 : kOOB);
+  }
+}
+
+template <int BM, int WAVES, bool HAS3>
+__device__ __forceinline__ void bneck_tail(const GemmArgs& g, const TailArgs& tz, float* __restrict__ lds, const f32x16& acc, const int m0) {
+  constexpr int WM = BM >= 64 ? 2 : 1, WN = 2;
+  static_assert(WAVES == WM * WN, "the tail runs on the 3x3's wave grid, no K parts");
+  constexpr int kBufT = BM * kRowPitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  float* sT = lds;
+  float* sY = lds + 2 * kBufT;
+  const int col = wn * 32 + l31;                                   // this lane's column inside a 64-column chunk
+  const int own_off = (wm * 32 + 4 * hi) * kRowPitch + l31;       // accumulator register 0 of this lane in a 32-deep A tile (k = its column)
+  {
+    const float sc = g.scale ? g.scale[col] : 1.f, sh = g.shift ? g.shift[col] : 0.f;
+    float* dst = sT + wn * kBufT + own_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * kRowPitch] = fmaxf(acc[r] * sc + sh, 0.f);
+  }
+  __syncthreads();
+  const int a_off = (wm * 32 + l31) * kRowPitch + 4 * hi;
+  const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(tz.w2, tz.w2_bytes), rw3 = make_rsrc(tz.w3, HAS3 ? tz.w3_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(tz.add, tz.add ? tz.add_bytes : 0u), ry = make_rsrc(tz.y, tz.y_bytes);
+  const __amdgpu_buffer_rsrc_t rsc2 = make_rsrc(tz.sc2, tz.sc2 ? (unsigned)tz.N2 * 4u : 0u), rsh2 = make_rsrc(tz.sh2, tz.sh2 ? (unsigned)tz.N2 * 4u : 0u);
+  const unsigned ldw2_4 = (unsigned)tz.ldw2 * 4u, ldw3_4 = (unsigned)tz.ldw3 * 4u, ldy4 = (unsigned)tz.ldy2 * 4u, lda4 = (unsigned)tz.ld_add2 * 4u;
+  const unsigned bv2 = (unsigned)(4 * hi) * ldw2_4 + (unsigned)col * 4u;           // + 64 c columns, + k rows (SGPR part)
+  const unsigned bv3 = (unsigned)(4 * hi) * ldw3_4 + (unsigned)col * 4u;           // + (64 c + k) rows
+  const unsigned row0 = (unsigned)(m0 + wm * 32 + 4 * hi);
+  const bool rows_ok = row0 < (unsigned)g.M;                       // rows past M further down fall off the descriptors' ends
+  const bool has_sc2 = tz.sc2 != nullptr;
+  f32x16 acc3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+  float bw2[32];
+  bneck_load_b(rw2, bv2, 0u, ldw2_4, true, bw2);
+  const int nchunks = tz.N2 >> 6;
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned ncol = (unsigned)(64 * c + col);
+    const unsigned vy = rows_ok ? (row0 * (unsigned)tz.ldy2 + ncol) * 4u : kOOB;
+    const unsigned va = rows_ok ? (row0 * (unsigned)tz.ld_add2 + ncol) * 4u : kOOB;
+    float ad[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ad[r] = buf_load1s(radd, va, (unsigned)((r & 3) + 8 * (r >> 2)) * lda4);
+    const float sc2r = buf_load1(rsc2, ncol * 4u), sh2 = buf_load1(rsh2, ncol * 4u);
+    const float sc2 = has_sc2 ? sc2r : 1.f;
+    float bw3[32];
+    if (HAS3) bneck_load_b(rw3, bv3, 64u * (unsigned)c, ldw3_4, true, bw3);
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    bneck_mfma64(sT, kBufT, a_off, bw2, acc2);
+    // the next chunk's expand fragments travel under this chunk's epilogue and reduce step (columns move by 256 bytes per chunk)
+    bneck_load_b(rw2, bv2 + 256u * (unsigned)(c + 1), 0u, ldw2_4, c + 1 < nchunks, bw2);
+    if (HAS3 && c > 0) __syncthreads();                            // every wave is done reading the previous chunk from sY
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+      const float v = fmaxf(acc2[r] * sc2 + sh2 + ad[r], 0.f);
+      buf_store1(ry, vy + rr * ldy4, v);
+      if (HAS3) sY[wn * kBufT + own_off + rr * kRowPitch] = v;
+    }
+    if (HAS3) {
+      __syncthreads();
+      bneck_mfma64(sY, kBufT, a_off, bw3, acc3);
+    }
+  }
+  if (HAS3) {
+    const __amdgpu_buffer_rsrc_t rt = make_rsrc(tz.t, tz.t_bytes);
+    const float sc3 = tz.sc3 ? tz.sc3[col] : 1.f, sh3 = tz.sh3 ? tz.sh3[col] : 0.f;
+    const unsigned vt = rows_ok ? (row0 * (unsigned)tz.ldt + (unsigned)col) * 4u : kOOB;
+    const unsigned ldt4 = (unsigned)tz.ldt * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      buf_store1(rt, vt + (unsigned)((r & 3) + 8 * (r >> 2)) * ldt4, fmaxf(acc3[r] * sc3 + sh3, 0.f));
+  }
+}
+
 // COH: the output is handed to other workgroups of the SAME launch (chain kernel): stores are write-through (sc1), as the
 // split-K slabs are, so that a consumer on another XCD finds them in memory.
 // PERSIST (batched launches, forward form, plain epilogue): the workgroup runs g.zper CONSECUTIVE problems of the batch on its output
@@ -284,9 +404,10 @@ constexpr int igemm_persist_scratch_floats() {
 // the finished accumulators leave with fire-and-forget stores, and the workgroup pays ONE prologue and ONE drain instead of one per
 // problem.  The 36 GEMMs of a Winograd layer have 4-8 K tiles each: as 432-720 one-tile workgroups they were all prologue and
 // epilogue.
-template <int BM, int BN, int BMODE, bool SMALLC, int WAVES, bool COH = false, bool PERSIST = false>
+// FUSE (1 / 2): the accumulators do not leave through the epilogue but feed bneck_tail (2: with the next block's 1x1 reduce)
+template <int BM, int BN, int BMODE, bool SMALLC, int WAVES, bool COH = false, bool PERSIST = false, int FUSE = 0>
 __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __restrict__ lds, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
-                                                const unsigned grid_x) {
+                                                const unsigned grid_x, [[maybe_unused]] const TailArgs* tz = nullptr) {
   constexpr int NT = 64 * WAVES;
   // Wave grid over the output tile: 2x2 for tiles of 64 rows / columns and more, a single wave row (column) for the 32-row
   // (32-column) tiles; the waves left over split every 32-deep K tile between them (KH parts: the 8-wave form of the 64x64
@@ -699,6 +820,11 @@ __device__ __forceinline__ void conv_igemm_body(const GemmArgs& g, float* __rest
     __syncthreads();
     live_out = khalf == 0;
   }
+  if constexpr (FUSE != 0) {
+    static_assert(BN == 64 && BMODE == 0 && !SMALLC && !COH && !PERSIST && KH == 1 && TM == 1 && TN == 1, "the fused tail follows a whole-K [BM x 64] forward tile");
+    bneck_tail<BM, WAVES, FUSE == 2>(g, *tz, lds, acc[0][0], m0);
+    return;
+  }
 #ifdef RADNET_DIAG_STAMPS
   t_loop = __builtin_amdgcn_s_memtime();
   // stamps go to a buffer of their own; nothing the kernel outputs is computed from them.  The epilogue stamp is
@@ -900,6 +1026,14 @@ __global__ void __launch_bounds__(64 * WAVES) conv_igemm_kernel(GemmArgs g) {
     return;
   }
   conv_igemm_body<BM, BN, BMODE, SMALLC, WAVES>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// 3x3 conv + the pointwise convs behind it (bneck_tail): one workgroup per BM output rows, all 64 channels of the 3x3
+template <int BM, int WAVES, int FUSE>
+__global__ void __launch_bounds__(64 * WAVES) conv_bneck_kernel(GemmArgs g, TailArgs tz) {
+  constexpr int kLds = igemm_lds_floats<BM, 64, 0>() > bneck_lds_floats<BM>() ? igemm_lds_floats<BM, 64, 0>() : bneck_lds_floats<BM>();
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  conv_igemm_body<BM, 64, 0, false, WAVES, false, false, FUSE>(g, lds, blockIdx.x, 0u, 0u, gridDim.x, &tz);
 }
 
 // Two INDEPENDENT forward problems as one launch (round 4: branch2a and the shortcut conv of a conv_block read the same input,
@@ -1972,7 +2106,7 @@ extern "C" int radnet_conv_fwd_pair(radnet_ctx* ctx, const radnet_conv_desc* d1,
     int r = run_igemm(ctx, a, 0, d1->c == 4, 0);
     return r != RADNET_OK ? r : run_igemm(ctx, b, 0, d2->c == 4, 0);
   };
-  static const bool disabled = getenv("RADNET_NO_FWD_PAIR") != nullptr;
+  static const bool disabled = radnet_env_flag("RADNET_NO_FWD_PAIR");
   const bool same_grid = g1.M == g2.M && g1.K == g2.K && g1.C == g2.C && g1.npos == g2.npos && g1.stride == g2.stride;
   if (disabled || !same_grid || d1->c == 4 || (g1.C % BK) != 0 || ctx->force_a > 0 || ctx->pair_capture != nullptr || !ctx->autotune) return separate();
   rc = prepare_igemm(ctx, g1, 0, false);
@@ -2023,6 +2157,94 @@ extern "C" int radnet_conv_fwd_pair(radnet_ctx* ctx, const radnet_conv_desc* d1,
   if (rc == RADNET_ERR_UNSUPPORTED) return separate();
   if (rc != RADNET_OK) return rc;
   radnet_timing_end_armed(ctx, 0, 2.0 * g1.M * (double)(g1.N + g2.N) * g1.K);
+  return RADNET_OK;
+}
+
+// The back of a bottleneck block as one launch (conv_bneck_kernel): db = its 3x3 conv (stride 1, 'same', 64 output channels, ReLU), dc = its
+// 1x1 expand on db's output (+ shortcut, ReLU), da = the NEXT block's 1x1 reduce on dc's output (64 columns, ReLU) or null.  db->y is NOT
+// written by the fused launch (frozen layers only).  Decided once per shape (kind 33 in the tuning table: slices 1 = fused with tile_a rows
+// per workgroup, 2 = the separate launches); anything the fused kernel does not take runs as the separate launches.
+extern "C" int radnet_conv_bottleneck(radnet_ctx* ctx, const radnet_conv_desc* db, const radnet_conv_desc* dc, const radnet_conv_desc* da) {
+  if (!ctx || !db || !dc) return RADNET_ERR_ARG;
+  auto separate = [&]() -> int {
+    int r = radnet_conv_fwd(ctx, db);
+    if (r == RADNET_OK) r = radnet_conv_fwd(ctx, dc);
+    if (r == RADNET_OK && da) r = radnet_conv_fwd(ctx, da);
+    return r;
+  };
+  static const bool disabled = radnet_env_flag("RADNET_NO_BNECK_FUSE");
+  const int M = db->nb * db->oh * db->ow;
+  auto pointwise = [&](const radnet_conv_desc* d, const radnet_conv_desc* src) {
+    return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->x == src->y && d->c == src->n &&
+           d->nb * d->oh * d->ow == M && d->act == 1 && d->y != nullptr && d->w != nullptr && (d->ldw & 3) == 0 && !((uintptr_t)d->w & 15);
+  };
+  bool ok = !disabled && ctx->autotune && ctx->force_a <= 0 && ctx->pair_capture == nullptr;
+  ok = ok && db->kh == 3 && db->kw == 3 && db->stride == 1 && db->pad_t == 1 && db->pad_l == 1 && db->n == 64 && db->act == 1 && !db->addend && db->y &&
+       db->c % BK == 0 && db->oh == db->h && db->ow == db->w_;
+  ok = ok && pointwise(dc, db) && dc->n % 64 == 0 && dc->ldw >= dc->n && dc->ldy >= dc->n && (!dc->addend || dc->ld_add >= dc->n);
+  ok = ok && (!da || (pointwise(da, dc) && da->n == 64 && !da->addend && da->ldw >= 64 && da->ldy >= 64));
+  ok = ok && (uint64_t)M * (uint64_t)std::max(dc->ldy, dc->ld_add) * 4ull < (1ull << 31);
+  if (!ok) return separate();
+  GemmArgs g;
+  int rc = fwd_args(ctx, db, g);
+  if (rc == RADNET_OK) rc = prepare_igemm(ctx, g, 0, false);
+  if (rc != RADNET_OK) return rc;
+  g.y = nullptr; g.y_bytes = 0;
+  TailArgs tz{};
+  tz.w2 = dc->w; tz.sc2 = dc->scale; tz.sh2 = dc->shift; tz.add = dc->addend; tz.y = dc->y;
+  tz.N2 = dc->n; tz.ldw2 = dc->ldw; tz.ldy2 = dc->ldy; tz.ld_add2 = dc->ld_add;
+  tz.w2_bytes = (unsigned)(((uint64_t)63 * dc->ldw + dc->n) * 4ull);
+  tz.y_bytes = (unsigned)(((uint64_t)(M - 1) * dc->ldy + dc->n) * 4ull);
+  tz.add_bytes = dc->addend ? (unsigned)(((uint64_t)(M - 1) * dc->ld_add + dc->n) * 4ull) : 0u;
+  if (da) {
+    tz.w3 = da->w; tz.sc3 = da->scale; tz.sh3 = da->shift; tz.t = da->y; tz.ldw3 = da->ldw; tz.ldt = da->ldy;
+    tz.w3_bytes = (unsigned)(((uint64_t)(dc->n - 1) * da->ldw + 64) * 4ull);
+    tz.t_bytes = (unsigned)(((uint64_t)(M - 1) * da->ldy + 64) * 4ull);
+  }
+  auto fused = [&](int bm) -> int {
+    dim3 grid(radnet_cdiv(M, bm));
+    if (bm == 64) {
+      if (da) RADNET_LAUNCH((conv_bneck_kernel<64, 4, 2>), grid, dim3(256), 0, ctx->stream, ctx->arm0, ctx->arm1, g, tz);
+      else RADNET_LAUNCH((conv_bneck_kernel<64, 4, 1>), grid, dim3(256), 0, ctx->stream, ctx->arm0, ctx->arm1, g, tz);
+    } else if (bm == 32) {
+      if (da) RADNET_LAUNCH((conv_bneck_kernel<32, 2, 2>), grid, dim3(128), 0, ctx->stream, ctx->arm0, ctx->arm1, g, tz);
+      else RADNET_LAUNCH((conv_bneck_kernel<32, 2, 1>), grid, dim3(128), 0, ctx->stream, ctx->arm0, ctx->arm1, g, tz);
+    } else {
+      return RADNET_ERR_UNSUPPORTED;
+    }
+    RADNET_CHECK_LAUNCH(ctx, "conv_bneck");
+    return RADNET_OK;
+  };
+  const radnet_shape_key key{33, M, dc->n * 65536 + (da ? 64 : 0), g.K, g.C, g.npos, g.stride};
+  auto it = ctx->tuned->find(key);
+  if (it == ctx->tuned->end()) {
+    rc = separate();                     // measures the layers' own shapes, if new
+    if (rc != RADNET_OK) return rc;
+    float best = 0.f;
+    rc = radnet_time_launches(ctx, separate, 12, &best);
+    if (rc != RADNET_OK) return rc;
+    radnet_tuned choice{64, 64, 2, best, 4};
+    for (int bm : {64, 32}) {
+      float m1 = 0.f, m2 = 0.f;
+      rc = radnet_time_launches(ctx, [&]() { return fused(bm); }, 12, &m1);
+      if (rc == RADNET_OK) rc = radnet_time_launches(ctx, [&]() { return fused(bm); }, 12, &m2);
+      if (rc != RADNET_OK) return rc;
+      const float ms = std::min(m1, m2);
+      if (getenv("RADNET_TUNE_LOG")) fprintf(stderr, "[radnet tune] bottleneck tail M=%d N2=%d%s: fused %d rows %.1f us\n", M, dc->n, da ? "+64" : "", bm, ms * 1e3);
+      if (ms < choice.ms) choice = radnet_tuned{bm, 64, 1, ms, 4};
+    }
+    (*ctx->tuned)[key] = choice;
+    if (getenv("RADNET_TUNE_LOG"))
+      fprintf(stderr, "[radnet tune] bottleneck tail M=%d N2=%d%s -> %s (%.1f us; the separate launches %.1f us)\n", M, dc->n, da ? "+64" : "",
+              choice.splits == 1 ? (choice.a == 64 ? "one launch, 64 rows" : "one launch, 32 rows") : "separate launches", choice.ms * 1e3, best * 1e3);
+    it = ctx->tuned->find(key);
+  }
+  if (it->second.splits != 1) return separate();
+  radnet_timing_arm(ctx);
+  rc = fused(it->second.a);
+  if (rc == RADNET_ERR_UNSUPPORTED) return separate();
+  if (rc != RADNET_OK) return rc;
+  radnet_timing_end_armed(ctx, 0, 2.0 * M * (64.0 * g.K + 64.0 * dc->n + (da ? 64.0 * dc->n : 0.0)));
   return RADNET_OK;
 }
 
@@ -2233,7 +2455,7 @@ extern "C" int radnet_conv_wgrad(radnet_ctx* ctx, const radnet_conv_desc* d) { r
 // launches in the order wgrad, dgrad.  Results are those of the separate launches (same kernels' code, same launch shapes).
 extern "C" int radnet_conv_bwd(radnet_ctx* ctx, const radnet_conv_desc* d) {
   if (!ctx || !d) return RADNET_ERR_ARG;
-  static const bool disabled = getenv("RADNET_NO_BWD_PAIR") != nullptr;
+  static const bool disabled = radnet_env_flag("RADNET_NO_BWD_PAIR");
   if (disabled || ctx->pair_capture != nullptr || !d->dx) {
     int rc = radnet_conv_wgrad(ctx, d);
     return rc != RADNET_OK || !d->dx ? rc : radnet_conv_dgrad(ctx, d);

@@ -85,6 +85,13 @@ extern "C" int radnet_program_run(radnet_ctx* ctx, const radnet_op* ops, int32_t
         if (k + 1 >= n_ops || ops[k + 1].kind != RADNET_OP_NOP) RADNET_FAIL(ctx, RADNET_ERR_ARG, "program: CONV_FWD_PAIR at %d without its second descriptor (a NOP slot)", k);
         rc = radnet_conv_fwd_pair(ctx, &o.conv, &ops[k + 1].conv);
         break;
+      case RADNET_OP_CONV_BNECK: {
+        const int extra = o.i[0] ? 2 : 1;
+        for (int e = 1; e <= extra; ++e)
+          if (k + e >= n_ops || ops[k + e].kind != RADNET_OP_NOP) RADNET_FAIL(ctx, RADNET_ERR_ARG, "program: CONV_BNECK at %d without its %d following descriptors (NOP slots)", k, extra);
+        rc = radnet_conv_bottleneck(ctx, &o.conv, &ops[k + 1].conv, o.i[0] ? &ops[k + 2].conv : nullptr);
+        break;
+      }
       case RADNET_OP_NOP: rc = RADNET_OK; break;
       case RADNET_OP_MAXPOOL:
         rc = radnet_maxpool_fwd(ctx, (const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5]);

@@ -145,6 +145,11 @@ void radnet_timing_arm(radnet_ctx* ctx);
 void radnet_timing_end_armed(radnet_ctx* ctx, int cls, double flops);
 
 static inline int radnet_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// environment switch: set and neither empty nor "0"
+static inline bool radnet_env_flag(const char* name) {
+  const char* v = getenv(name);
+  return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
+}
 
 // Autotune helper: one warm-up launch, then `iters` launches bracketed by HIP events on the ctx stream.
 template <typename F>

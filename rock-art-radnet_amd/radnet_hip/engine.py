@@ -167,6 +167,8 @@ class FasterRCNNEngine:
         self.use_chain = os.environ.get("RADNET_CHAIN", "0") == "1"
         # branch2a + shortcut conv of a conv_block as one call (radnet_conv_fwd_pair decides per shape pair whether one launch is faster)
         self.fwd_pair = os.environ.get("RADNET_NO_FWD_PAIR", "0") != "1"      # (a base plan built for the chain kernel keeps the single convs)
+        # frozen stage-2 blocks: 3x3 + 1x1 expand (+ the next block's 1x1 reduce) as one call (radnet_conv_bottleneck decides per shape)
+        self.bneck_fuse = os.environ.get("RADNET_NO_BNECK_FUSE", "0") != "1"
         # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
         # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
@@ -518,11 +520,45 @@ class FasterRCNNEngine:
                 out = buf(nb, oh, ow, f3)
                 d, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", d))
                 cur, h, w = out, oh, ow
+        if self.bneck_fuse and not self.use_chain and self.FROZEN_BASE_FUSION:
+            ops = self._fuse_bottlenecks(ops)
         plan = dict(ops=ops, x=x, F=cur, fh=h, fw=w, keep=keep, nb=nb)
         if self.use_chain:
             self._chain_ops(plan, first=2)               # conv1 (4-channel stem) and the max-pool stay launches of their own
         self._plans[key] = plan
         return plan
+
+    FROZEN_BASE_FUSION = True          # nn_base's stage 2 is frozen in every mode this engine runs (train.py, cont_train.py: stages 3-4 only)
+
+    @staticmethod
+    def _fuse_bottlenecks(ops):
+        """3x3 conv (64 -> 64 channels) + the 1x1 expand on its output (+ the next block's 1x1 reduce on THAT output) -> one
+        radnet_conv_bottleneck call: the 3x3's output and the expand's re-read never touch memory.  Only where the 3x3 output has no other
+        reader in the list (it is not written any more) -- stage 2 of nn_base (resnet50.py:197-199)."""
+        def conv(i):
+            return ops[i][1] if i < len(ops) and ops[i][0] == "conv" else None
+
+        def reads(d, ptr):
+            return ptr in (getattr(d, "x", None), getattr(d, "addend", None))
+
+        out, k = [], 0
+        while k < len(ops):
+            db, dc = conv(k), conv(k + 1)
+            ok = (db is not None and dc is not None and db.kh == 3 and db.stride == 1 and db.n == 64 and db.c % 32 == 0 and not db.addend and db.act == 1
+                  and dc.kh == 1 and dc.stride == 1 and dc.x == db.y and dc.c == 64 and dc.n % 64 == 0 and dc.act == 1)
+            if ok:                                  # nobody else may read the tensor that is no longer written
+                ok = not any(reads(p, db.y) for j, (kind, p) in enumerate(ops) if j != k + 1 and kind in ("conv", "conv_pair_first", "conv_pair_second"))
+                ok = ok and not any(kind in ("wino", "wino_reuse") and p[0] == db.y for kind, p in ops)
+            if not ok:
+                out.append(ops[k])
+                k += 1
+                continue
+            da = conv(k + 2)
+            if da is not None and not (da.kh == 1 and da.stride == 1 and da.x == dc.y and da.c == dc.n and da.n == 64 and not da.addend and da.act == 1):
+                da = None
+            out += [("bneck_first", db), ("bneck_second", dc)] + ([("bneck_third", da)] if da is not None else [])
+            k += 3 if da is not None else 2
+        return out
 
     def _chain_ops(self, plan, first=0):
         """Replace plan['ops'][first:] by ONE persistent launch (radnet_chain_build, include/radnet_hip.h): the same
@@ -707,6 +743,13 @@ class FasterRCNNEngine:
                 o.kind = L.OP_CONV_FWD_PAIR         # descriptor rides in the following NOP slot
                 o.conv = p
             elif kind == "conv_pair_second":
+                o.kind = L.OP_NOP
+                o.conv = p
+            elif kind == "bneck_first":             # 3x3 + 1x1 expand (+ next 1x1 reduce): one call, the other descriptors ride in the NOP slots behind
+                o.kind = L.OP_CONV_BNECK
+                o.conv = p
+                o.i[0] = 1 if k + 2 < len(ops) and ops[k + 2][0] == "bneck_third" else 0
+            elif kind in ("bneck_second", "bneck_third"):
                 o.kind = L.OP_NOP
                 o.conv = p
             elif kind in ("conv", "dgrad", "wgrad"):

@@ -122,18 +122,24 @@ class ContEngine(FasterRCNNEngine):
                 ca, cb, cc = self.convs[b + "2a"], self.convs[b + "2b"], self.convs[b + "2c"]
                 oh, ow = ((h - 1) // ca.stride + 1, (w - 1) // ca.stride + 1)
                 a = buf(nb, oh, ow, f1); da, _, _ = self._desc(ca, cur, nb, h, w, a); ops.append(("conv", da))
-                bb = buf(nb, oh, ow, f2); db, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", db))
                 ds = None
                 if first:
-                    sc = buf(nb, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False); ops.append(("conv", ds))
+                    sc = buf(nb, oh, ow, f3); ds, _, _ = self._desc(self.convs[b + "1"], cur, nb, h, w, sc, relu=False)
+                    if st < 3:                     # frozen stem: the shortcut first, so that 3x3 + expand (+ next reduce) are neighbours (_fuse_bottlenecks)
+                        ops.append(("conv", ds))
                 else:
                     sc = cur
+                bb = buf(nb, oh, ow, f2); db, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", db))
+                if first and st >= 3:
+                    ops.append(("conv", ds))
                 out = buf(nb, oh, ow, f3); dc, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", dc))
                 if st >= 3:
                     blocks.append(dict(st=st, first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, h=h, w=w, oh=oh, ow=ow,
                                        cin=ca.cin, f=(f1, f2, f3), stride=ca.stride, names=(b + "2a", b + "2b", b + "2c", b + "1")))
                 cur, h, w = out, oh, ow
         F = cur
+        if self.bneck_fuse and not self.use_chain:
+            stem[:] = self._fuse_bottlenecks(stem)
         dF = buf(nb * h * w, 1024)                # dL/dF, the producer's ReLU mask (F > 0) already applied
         bwd = self._blocks_backward(blocks, dF, nb, buf, lowest_stage=3)
         plan = dict(ops=stem + s34, ops_stem=stem, ops_s34=s34, bwd34=bwd, x=x, F=F, dF=dF, fh=h, fw=w, keep=keep, blocks=blocks)

@@ -51,6 +51,9 @@ def neighbours(key, cur):
     kind, m, n, k, c, npos, stride = key
     a, b, s, _, w = cur
     out = []
+    if kind == 33:      # radnet_conv_bottleneck's decision: the fused launch with a rows per workgroup (slices 1) or the separate launches (slices 2)
+        cands = [(64, 64, 1, 4), (32, 64, 1, 4), (a, b, 2, 4)]
+        return [o for o in cands if o != (a, b, s, w) and not (s == 2 and o[2] == 2)]
     if kind == 32:      # radnet_conv_fwd_pair's decision for a pair of shapes: one launch on tile a x b (slices 1) or the two launches (slices 2)
         cands = [(64, 64, 1, 4), (32, 64, 1, 4), (32, 32, 1, 4), (a, b, 2, 4)]
         return [o for o in cands if o != (a, b, s, w) and not (s == 2 and o[2] == 2)]
@@ -146,12 +149,13 @@ def cache_path(network, workload, H, W, per_batch, device_name, cache_dir=None):
 
 
 def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, gain=0.0025, wide=False, n_prime=18, log=print,
-         measure=None, comm=None, sync=None, only_new=False):
+         measure=None, comm=None, sync=None, only_new=False, kinds=None):
     """Walk `eng`'s launch-shape table against the throughput of the workload.
     measure(n) -> microseconds per step over n steps (default: run(20) untimed, then run(n) between two device synchronisations);
     comm: NoComm / DistComm (multi-rank jobs: rank 0 decides, see DistComm); sync(): device synchronisation (default torch's).
     only_new: walk only the shapes the engine measures during the first n_prime steps of THIS call (a job whose engine already
     holds shipped tables for other workloads: entries the job never launches are left alone).
+    kinds: walk only entries of these kinds (first field of the key), e.g. (33,) after a new fused launch has been added.
 
     run(n): enqueue n steps of the workload (the caller's loop over TrainStep.step with its lookahead); flush(): drain it.
     The engine must come without tables of its own (RADNET_SHIPPED_TUNING=0) and must not have run the workload yet: the shapes
@@ -216,7 +220,7 @@ def tune(eng, run, flush, out, passes=1, steps=200, budget_s=900.0, start=None, 
         n_acc = 0
         # longest launches first: ms x (how often is unknown) -- the per-launch time is the proxy
         for key in sorted(tab, key=lambda kk: -tab[kk][3]):
-            if walk is not None and key not in walk:
+            if (walk is not None and key not in walk) or (kinds is not None and key[0] not in kinds):
                 continue
             cur = list(tab[key])
             for cand in neighbours(key, cur):

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
 
 # ---- layer programs and composed entry points (include/radnet_hip.h, csrc/program.hip) --------------------------------
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_MAXPOOL, OP_COLSUM, OP_WINO, OP_WINO_REUSE, OP_WINO_WGRAD, OP_SCATTER, OP_FILL0, \
-    OP_RELU_MASK, OP_ROI_BWD, OP_CONV_BWD, OP_CHAIN, OP_CONV_FWD_PAIR = range(1, 16)
+    OP_RELU_MASK, OP_ROI_BWD, OP_CONV_BWD, OP_CHAIN, OP_CONV_FWD_PAIR, OP_CONV_BNECK = range(1, 17)
 OP_NOP = 0
 
 
@@ -169,6 +169,7 @@ def load_library():
         "radnet_conv_wgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_conv_bwd": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_conv_fwd_pair": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
+        "radnet_conv_bottleneck": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
         "radnet_colsum": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i32]),
         "radnet_maxpool_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),
         "radnet_roi_resize_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, i32, vp]),

@@ -775,3 +775,65 @@ def test_conv_fwd_pair_equals_the_two_convolutions(ctx, case):
         ctx.check(ctx.lib.radnet_conv_fwd_pair(ctx.h, C.byref(descs[0]), C.byref(descs[1])), "conv_fwd_pair")
         for y, ref in outs:
             close(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("rows", [64, 32])
+@pytest.mark.parametrize("case", [(1, 37, 53, 64, 256, True), (2, 19, 23, 64, 256, False), (1, 8, 9, 64, 128, True), (1, 150, 250, 64, 256, True)])
+def test_conv_bottleneck_equals_the_separate_convolutions(ctx, tmp_path, case, rows):
+    """radnet_conv_bottleneck (round 4: the back of a frozen stage-2 block -- 3x3, 1x1 expand + shortcut, the next block's 1x1 reduce -- as
+    ONE launch that passes the two intermediate tiles through LDS): the fused kernel, pinned through a tuning-table entry (kind 33) for
+    both of its row counts, against the oracle and against the three separate launches; ragged row edges, two images, N2 = 128 / 256,
+    with and without the trailing reduce; the 3x3's own output buffer stays untouched by the fused launch."""
+    from radnet_hip import lib as L
+    from oracle import dense
+    nb, h, w, c, n2, with_next = case
+    rs = np.random.RandomState(sum(case[:5]) + rows)
+    M = nb * h * w
+    x = np.maximum(rs.standard_normal((nb, h, w, c)), 0).astype(np.float32)
+    short = rs.standard_normal((nb, h, w, n2)).astype(np.float32)
+
+    def layer(k, cin, n):
+        wt = (rs.standard_normal((k, k, cin, n)) / np.sqrt(k * k * cin)).astype(np.float32)
+        return wt, rs.uniform(0.5, 1.5, n).astype(np.float32), (0.1 * rs.standard_normal(n)).astype(np.float32)
+
+    wb, sb, bb = layer(3, c, 64)
+    wc, scc, bc = layer(1, 64, n2)
+    wa, sa, ba = layer(1, n2, 64)
+    t2 = np.maximum(dense.conv2d(x.astype(np.float64), wb.astype(np.float64), None, 1, (1, 1, 1, 1)) * sb + bb, 0)
+    y_ref = np.maximum(dense.conv2d(t2, wc.astype(np.float64), None, 1, (0,) * 4) * scc + bc + short, 0)
+    t_ref = np.maximum(dense.conv2d(y_ref, wa.astype(np.float64), None, 1, (0,) * 4) * sa + ba, 0)
+    xd, shd = dev(x), dev(short)
+    dv = [dev(a) for a in (wb.reshape(-1, 64), sb, bb, wc.reshape(-1, n2), scc, bc, wa.reshape(-1, 64), sa, ba)]
+
+    def run(fused):
+        c2 = L.Context(0)
+        c2.check(c2.lib.radnet_set_workspace(c2.h, ctx._ws.data_ptr(), ctx._ws.numel()), "ws")
+        c2.check(c2.lib.radnet_set_autotune(c2.h, 1), "autotune")
+        table = tmp_path / ("t%d.txt" % fused)
+        table.write_text("# radnet tuned GEMM launch shapes v2\n33 %d %d %d %d 9 1 %d 64 %d 0.01 4\n"
+                         % (M, n2 * 65536 + (64 if with_next else 0), 9 * c, c, rows, 1 if fused else 2))
+        c2.check(c2.lib.radnet_tune_load(c2.h, str(table).encode()), "tune_load")
+        t2d = torch.full((nb, h, w, 64), float("nan"), dtype=torch.float32, device="cuda")
+        yd = torch.full((nb, h, w, n2), float("nan"), dtype=torch.float32, device="cuda")
+        td = torch.full((nb, h, w, 64), float("nan"), dtype=torch.float32, device="cuda")
+        db = conv_desc(L, xd, dv[0], t2d, nb, h, w, c, h, w, 3, 1, 1, 64, 64, dv[1], dv[2], None, 1)
+        dc = conv_desc(L, t2d, dv[3], yd, nb, h, w, 64, h, w, 1, 1, 0, n2, n2, dv[4], dv[5], shd, 1)
+        da = conv_desc(L, yd, dv[6], td, nb, h, w, n2, h, w, 1, 1, 0, 64, 64, dv[7], dv[8], None, 1)
+        for rep in range(2):
+            c2.check(c2.lib.radnet_conv_bottleneck(c2.h, C.byref(db), C.byref(dc), C.byref(da) if with_next else None), "conv_bottleneck")
+        torch.cuda.synchronize()
+        out = t2d.cpu().numpy(), yd.cpu().numpy(), td.cpu().numpy()
+        c2.close()
+        return out
+
+    t2_f, y_f, t_f = run(True)
+    t2_s, y_s, t_s = run(False)
+    assert np.isnan(t2_f).all() and not np.isnan(t2_s).any()         # fused: the 3x3 output never reaches memory
+    close(t2_s, t2)
+    close(y_f, y_ref); close(y_s, y_ref)
+    np.testing.assert_allclose(y_f, y_s, rtol=0, atol=2e-6 * np.abs(y_ref).max())
+    if with_next:
+        close(t_f, t_ref); close(t_s, t_ref)
+        np.testing.assert_allclose(t_f, t_s, rtol=0, atol=4e-6 * np.abs(t_ref).max())
+    else:
+        assert np.isnan(t_f).all() and np.isnan(t_s).all()

@@ -19,6 +19,9 @@ def _valid(key, a, b, s, w):
     if kind == 32:                                                   # forward pair (branch2a + shortcut): one launch on that tile, or two
         assert (a, b) in ((64, 64), (32, 64), (32, 32)) and s in (1, 2) and w == 4, (key, a, b, s, w)
         return
+    if kind == 33:                                                   # bottleneck tail (3x3 + 1x1 expand [+ next 1x1 reduce]): fused on a rows, or separate
+        assert (a, b) in ((64, 64), (32, 64)) and s in (1, 2) and w == 4 and npos == 9 and n % 65536 in (0, 64), (key, a, b, s, w)
+        return
     wgrad = (kind & 7) in (2, 3)
     small = (a, b) in ((32, 64), (32, 32))                           # round 4: 32-row tiles of the forward / data-gradient kernel, 4 waves
     assert (small and not wgrad and w == 4) or (a in (64, 128) and b in (64, 128)), (key, a, b, w)

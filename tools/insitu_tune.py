@@ -25,7 +25,9 @@ def main():
     ap.add_argument("--network", choices=("resnet50", "vgg16"), default="resnet50")
     ap.add_argument("--workload", choices=("train", "predict"), default="train", help="predict = RADNet.predict's tile loop (cfg 3)")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="images per step (2 = BASELINE cfg 4 on one GPU)")
+    ap.add_argument("--kinds", default=None, help="comma-separated entry kinds to walk (default: all), e.g. 32,33 = the paired / fused launch decisions")
     args = ap.parse_args()
+    kinds = tuple(int(v) for v in args.kinds.split(",")) if args.kinds else None
     os.environ["RADNET_SHIPPED_TUNING"] = "0"      # start from what the engine measures itself (or --start), never from a shipped table
     sys.path[:0] = [ROOT, os.path.join(ROOT, "rock-art-radnet_amd")]
     import torch
@@ -51,7 +53,7 @@ def main():
                 n -= len(tiles)
 
         before, after, changed = insitu.tune(eng, run, lambda: None, args.out, passes=args.passes, steps=args.steps, budget_s=args.budget_s,
-                                             start=args.start, gain=args.gain, wide=args.wide, n_prime=8, log=lambda m: print(m, flush=True))
+                                             start=args.start, gain=args.gain, wide=args.wide, n_prime=8, log=lambda m: print(m, flush=True), kinds=kinds)
         print("in situ: tile %.1f -> %.1f us (%.1f -> %.1f tiles/s), %d entries changed" % (before, after, 1e6 / before, 1e6 / after, len(changed)))
         for key, cand in changed:
             print("  changed %s -> tile %dx%d slices %d waves %d" % (key, cand[0], cand[1], cand[2], cand[3]))
@@ -97,7 +99,7 @@ def main():
 
     before, after, changed = insitu.tune(eng, run, ts.flush, args.out, passes=args.passes, steps=args.steps, budget_s=args.budget_s,
                                          start=args.start, gain=args.gain, wide=args.wide, n_prime=2 * getattr(ts, "NBUF", 6) + 6,
-                                         log=lambda m: print(m, flush=True))
+                                         log=lambda m: print(m, flush=True), kinds=kinds)
     per = args.per_gpu_batch
     print("in situ: step %.1f -> %.1f us (%.1f -> %.1f images/s), %d entries changed" % (before, after, per * 1e6 / before, per * 1e6 / after, len(changed)))
     for key, cand in changed:
