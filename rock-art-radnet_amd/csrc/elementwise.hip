@@ -112,58 +112,71 @@ __global__ void __launch_bounds__(256) roi_resize_bwd_kernel(const float* __rest
 }
 
 // Ordered form of the same gradient (radnet_ctx::deterministic): overlapping RoIs add into the same feature-map pixel, and
-// the atomics above add them in whatever order the workgroups run.  Here a workgroup (one wave) OWNS one feature-map row and
-// 64 channels: it walks the RoIs, their output rows and output columns in index order, adds the taps that land in its row
-// into an LDS copy of the row (lane = channel, so every address has one writer with one program order) and adds the copy
-// to dfmap once at the end.
-__global__ void __launch_bounds__(64) roi_resize_bwd_ordered_kernel(const float* __restrict__ dy, int H, int W, int C,
-                                                                    const float* __restrict__ rois, int R, int ps, float* __restrict__ dfmap) {
-  extern __shared__ float row[];                // [W][64]
-  const int y = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
-  const bool live = c < C;
-  for (int x = 0; x < W; ++x) row[x * 64 + threadIdx.x] = 0.f;
-  bool touched = false;
-  for (int r = 0; r < R; ++r) {
-    const RoiGeom g = roi_geom(rois + 4 * r, H, W);
-    if (g.cw <= 0 || g.ch <= 0 || y < g.y0 || y >= g.y0 + g.ch) continue;      // uniform for the workgroup
-    const float hs = (float)g.ch / (float)ps, ws = (float)g.cw / (float)ps;
-    for (int oy = 0; oy < ps; ++oy) {
-      const float sy = (float)oy * hs;
-      const int ylo = (int)floorf(sy), yhi = min(ylo + 1, g.ch - 1);
-      const float ly = sy - (float)ylo;
-      const bool top = g.y0 + ylo == y, bot = g.y0 + yhi == y;
-      if (!top && !bot) continue;
-      touched = true;
-      // the ps values of this output row first, all loads in flight together (one at a time this loop ran at one memory
-      // round trip per output pixel: 218 us for 20 RoIs at 38x63), then the adds in column order
-      constexpr int kMaxPs = 14;
-      float vrow[kMaxPs];
-      const float* src = dy + ((long long)(r * ps + oy) * ps) * C + c;
-#pragma unroll
-      for (int ox = 0; ox < kMaxPs; ++ox) vrow[ox] = (live && ox < ps) ? src[(long long)ox * C] : 0.f;
-#pragma unroll
-      for (int ox = 0; ox < kMaxPs; ++ox) {
-        if (ox >= ps) break;
+// the atomics above add them in whatever order the workgroups run.  Here the sum is GATHERED: a workgroup owns one feature-map pixel
+// (all channels, four per thread) and walks the RoIs, their output rows and output columns in index order; a tap that lands on its pixel
+// is added to a register.  Every decision (does RoI r cover the pixel, is output row oy / column ox one of its two neighbours) is the
+// forward kernel's own float arithmetic on wave-uniform values, so the loops are scalar branches; only taps that hit cost a load.  The
+// order of the additions is a function of the RoI list alone; products are rounded before they are added (no contraction into an FMA:
+// the result does not depend on how the compiler schedules the chain).
+// (Round 4.  The form before this one gave a workgroup a feature-map ROW in LDS and walked the RoIs with one wave: ~40 dependent memory
+// round trips per row, then 63 dependent read-modify-writes of the row -- 100-165 us for 20 RoIs on the 38x63 map against 50 us for the
+// atomics; return-less LDS adds and four waves per row changed nothing, tools/roi_bwd_timing.py.)
+__global__ void __launch_bounds__(256) roi_resize_bwd_ordered_kernel(const float* __restrict__ dy, int H, int W, int C4,
+                                                                     const float* __restrict__ rois, int R, int ps, float* __restrict__ dfmap) {
+  const int y = blockIdx.x / W, x = blockIdx.x - y * W;
+  const float4* src = reinterpret_cast<const float4*>(dy);
+  for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool touched = false;
+    auto add = [&](const float4& v, float wy, float wx) {
+      acc.x = __fadd_rn(acc.x, __fmul_rn(__fmul_rn(v.x, wy), wx));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(__fmul_rn(v.y, wy), wx));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(__fmul_rn(v.z, wy), wx));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(__fmul_rn(v.w, wy), wx));
+    };
+    for (int r = 0; r < R; ++r) {
+      const RoiGeom g = roi_geom(rois + 4 * r, H, W);
+      if (g.cw <= 0 || g.ch <= 0 || y < g.y0 || y >= g.y0 + g.ch || x < g.x0 || x >= g.x0 + g.cw) continue;
+      const float hs = (float)g.ch / (float)ps, ws = (float)g.cw / (float)ps;
+      // output columns whose low / high neighbour is this pixel's column (bit ox)
+      unsigned lo_mask = 0u, hi_mask = 0u;
+      for (int ox = 0; ox < ps; ++ox) {
         const float sx = (float)ox * ws;
         const int xlo = (int)floorf(sx), xhi = min(xlo + 1, g.cw - 1);
-        const float lx = sx - (float)xlo;
-        const float v = vrow[ox];
-        float* lo = row + (g.x0 + xlo) * 64 + threadIdx.x;
-        float* hi = row + (g.x0 + xhi) * 64 + threadIdx.x;
-        if (top) {
-          *lo += v * (1.f - ly) * (1.f - lx);
-          *hi += v * (1.f - ly) * lx;
-        }
-        if (bot) {
-          *lo += v * ly * (1.f - lx);
-          *hi += v * ly * lx;
+        lo_mask |= (g.x0 + xlo == x ? 1u : 0u) << ox;
+        hi_mask |= (g.x0 + xhi == x ? 1u : 0u) << ox;
+      }
+      const unsigned any_mask = lo_mask | hi_mask;
+      if (any_mask == 0u) continue;
+      for (int oy = 0; oy < ps; ++oy) {
+        const float sy = (float)oy * hs;
+        const int ylo = (int)floorf(sy), yhi = min(ylo + 1, g.ch - 1);
+        const float ly = sy - (float)ylo;
+        const bool top = g.y0 + ylo == y, bot = g.y0 + yhi == y;
+        if (!top && !bot) continue;
+        const float4* rowp = src + ((long long)(r * ps + oy) * ps) * C4 + c4;
+        for (unsigned m = any_mask; m != 0u; m &= m - 1u) {
+          const int ox = __builtin_ctz(m);
+          const float sx = (float)ox * ws;
+          const float lx = sx - (float)(int)floorf(sx);
+          const bool lo = (lo_mask >> ox) & 1u, hi = (hi_mask >> ox) & 1u;
+          const float4 v = rowp[(long long)ox * C4];
+          touched = true;
+          // the order the scatter forms use for one pixel: top-low, top-high, bottom-low, bottom-high
+          if (top && lo) add(v, 1.f - ly, 1.f - lx);
+          if (top && hi) add(v, 1.f - ly, lx);
+          if (bot && lo) add(v, ly, 1.f - lx);
+          if (bot && hi) add(v, ly, lx);
         }
       }
     }
+    if (touched) {
+      float4* dst = reinterpret_cast<float4*>(dfmap) + (long long)blockIdx.x * C4 + c4;
+      float4 d = *dst;
+      d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+      *dst = d;
+    }
   }
-  if (!touched || !live) return;
-  float* dst = dfmap + (long long)y * W * C + c;
-  for (int x = 0; x < W; ++x) dst[(long long)x * C] += row[x * 64 + threadIdx.x];
 }
 
 // ---- AveragePooling2D((7,7)) + Flatten over the RoI axis (resnet50.py:260-261) ----------------------
@@ -607,9 +620,8 @@ extern "C" int radnet_roi_resize_fwd(radnet_ctx* ctx, const float* fmap, int32_t
 extern "C" int radnet_roi_resize_bwd(radnet_ctx* ctx, const float* dy, int32_t h, int32_t w, int32_t c, const float* rois, int32_t r,
                                      int32_t ps, float* dfmap) {
   if (!ctx || !dy || !rois || !dfmap) return RADNET_ERR_ARG;
-  const size_t smem = (size_t)w * 64 * sizeof(float);
-  if (ctx->deterministic && smem <= 64 * 1024 && ps <= 14)
-    hipLaunchKernelGGL(roi_resize_bwd_ordered_kernel, dim3(h, radnet_cdiv(c, 64)), dim3(64), smem, ctx->stream, dy, h, w, c, rois, r, ps, dfmap);
+  if (ctx->deterministic && (c % 4) == 0 && ps <= 32 && (long long)h * w < (1ll << 31))
+    hipLaunchKernelGGL(roi_resize_bwd_ordered_kernel, dim3(h * w), dim3(256), 0, ctx->stream, dy, h, w, c / 4, rois, r, ps, dfmap);
   else
     hipLaunchKernelGGL(roi_resize_bwd_kernel, dim3(r * ps * ps), dim3(256), 0, ctx->stream, dy, h, w, c, rois, ps, dfmap);
   RADNET_CHECK_LAUNCH(ctx, "roi_resize_bwd");

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Ordered kernel list of one steady-state step from a rocprofv3 --kernel-trace CSV (one-lane run): start offset, duration,
-gap to the previous kernel's end, grid / workgroup size, kernel name.  usage: trace_sequence.py <kernel_trace.csv>"""
+gap to the previous kernel's end, grid / workgroup size, kernel name.  usage: trace_sequence.py <kernel_trace.csv> [adam launches per step, default 2]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-s, e = idx[-7] + 1, idx[-5] + 1
+NA = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() and int(sys.argv[2]) <= 8 else 2
+s, e = idx[-5 - NA] + 1, idx[-5] + 1
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:56]

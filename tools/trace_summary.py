@@ -6,7 +6,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 idx = [i for i, n in enumerate(names) if 'adam_kernel' in n]
-s, e = idx[-7] + 1, idx[-5] + 1            # a full steady-state step: two Adam launches; the last steps lack the next-batch prefetch
+import os
+NA = int(os.environ.get('ADAMS_PER_STEP', '2'))
+s, e = idx[-5 - NA] + 1, idx[-5] + 1            # a full steady-state step: two Adam launches; the last steps lack the next-batch prefetch
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:60]
