@@ -250,6 +250,18 @@ int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, float* v, in
 int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1, float beta2,
                             float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len, const float* scale,
                             const float* t0, float* shift);
+/* radnet_adam_step_affine (shift may be 0: no bias re-fold) that ALSO rewrites the Winograd F(4x4,3x3) filter transforms of up to four
+ * 3x3 kernels that live in the arena -- dense [3][3][c][n] at float offset `off` -- into u [36][c][n], from the weights it has just
+ * updated: the arithmetic of radnet_winograd4_filter on the new weights, in the optimizer's pass (the classifier's three 3x3 convs run
+ * their training forward on U; a transform launch per layer and update cost the step what the Winograd forward gives). */
+typedef struct radnet_adam_wino {
+  int64_t off;           /* float offset of the kernel in the arena (multiple of 4) */
+  int32_t c, n;          /* input / output channels; the kernel is dense: ldw == n  */
+  float* u;              /* [36][c][n]                                              */
+} radnet_adam_wino;
+int radnet_adam_step_fused(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1, float beta2,
+                           float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len, const float* scale,
+                           const float* t0, float* shift, const radnet_adam_wino* layers, int32_t n_layers);
 
 /* ---- proposal decode + greedy NMS (rpn.py:68-172, 299-344, 380-455), fp64 ---------------------
  * pred: fused head output [rows*cols][ld_pred] (scores in [0,A), regression in [A,5A)).
@@ -490,6 +502,7 @@ typedef struct radnet_train_desc {
   const radnet_op* head_bwd_ops; int32_t n_head_bwd;
   float* head_shift; const float* head_scale; const float* head_bias; const float* head_t0; int64_t head_bias_len;
   void* tail_scratch;      /* unused (the head descriptor carries the scratch); kept for layout stability */
+  const radnet_adam_wino* head_wino; int32_t n_head_wino;   /* classifier 3x3 kernels whose training forward runs on Winograd filters: Adam #2 rewrites them (radnet_adam_step_fused) */
 } radnet_train_desc;
 int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, const radnet_host_hooks* hooks, float* losses5,
                       int32_t* took_head_step);

@@ -2,6 +2,7 @@
 // dense heads, losses (forward value + gradient in one pass), bias-gradient column sums, Adam.
 // Each stands in for a TensorFlow op the reference graph invokes implicitly; citations inline.
 #include "radnet_internal.h"
+#include "radnet_wino4.h"
 
 namespace {
 
@@ -344,13 +345,21 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
 // aff_*: optionally (radnet_adam_step_affine) the folded epilogue shifts of the convs whose biases live in [aff_off4, aff_off4 + aff_n4)
 // float4 chunks of the arena are refreshed from the just-updated biases in the same pass: shift = scale * bias + t0
 // (FixedBatchNormalization.py:59-85 folded; one launch fewer on the classifier lane per step).
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps,
-                                                   float gs, int zero_grad, long long aff_off4, long long aff_n4,
-                                                   const float* __restrict__ aff_scale, const float* __restrict__ aff_t0, float* __restrict__ aff_shift) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+// wz: optionally (radnet_adam_step_fused) 3x3 kernels [3][3][C][N] inside the arena whose Winograd F(4x4,3x3) transform U = G g G^T
+// [36][C][N] is rewritten in the same launch.  Those kernels are taken out of the flat sweep and given to workgroups of their own, behind
+// the sweep's in the grid: a workgroup owns 64 consecutive float4 chunks (c, 4 n) of a layer with all nine taps -- phase 1, every thread:
+// the Adam update of its share of the 9 x 64 chunks, coalesced, new weights also into LDS; phase 2, one thread per chunk: the transform
+// of its nine float4 values, wino4_filter_kernel's code, 36 coalesced 16-byte stores.  The transformed filters cost their own
+// bytes (4x the kernels') and no launch (three launches cost the classifier lane as much as the Winograd forward gives: DESIGN.md 4).
+struct AdamWino {
+  long long off4[4];     // first float4 of the layer's kernel in the arena
+  int cn4[4];            // C * N / 4: float4 chunks per tap (a multiple of 64)
+  int unit0[5];          // first workgroup (relative to the first Winograd workgroup) of each layer; [n] = their total
+  float* u[4];
+  int n;
+  unsigned sweep_blocks; // workgroups of the flat sweep (the Winograd workgroups follow)
+};
+__device__ __forceinline__ void adam_one(float4& pp, const float4& gg, float4& mm, float4& vv, float lr_t, float b1, float b2, float eps, float gs) {
 #define ADAM1(q)                                         \
   {                                                      \
     float gq = gg.q * gs;                                \
@@ -358,12 +367,71 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
     vv.q = b2 * vv.q + (1.f - b2) * gq * gq;             \
     pp.q = pp.q - lr_t * mm.q / (sqrtf(vv.q) + eps);     \
   }
-    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+  ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
-    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps,
+                                                   float gs, int zero_grad, long long aff_off4, long long aff_n4,
+                                                   const float* __restrict__ aff_scale, const float* __restrict__ aff_t0, float* __restrict__ aff_shift,
+                                                   AdamWino wz) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  if (wz.n > 0 && blockIdx.x >= wz.sweep_blocks) {
+    __shared__ float4 taps[9][64];
+    const int unit = (int)(blockIdx.x - wz.sweep_blocks);
+    int layer = 0;
+    for (int l = 1; l < wz.n; ++l)
+      if (unit >= wz.unit0[l]) layer = l;
+    const int cn4 = wz.cn4[layer];
+    const long long j0 = (long long)(unit - wz.unit0[layer]) * 64;
+    for (int it = threadIdx.x; it < 9 * 64; it += 256) {
+      const int tap = it >> 6, jj = it & 63;
+      const long long k = wz.off4[layer] + (long long)tap * cn4 + j0 + jj;
+      float4 pp = p4[k], mm = m4[k], vv = v4[k];
+      adam_one(pp, g4[k], mm, vv, lr_t, b1, b2, eps, gs);
+      p4[k] = pp; m4[k] = mm; v4[k] = vv;
+      if (zero_grad) g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      taps[tap][jj] = pp;
+    }
+    __syncthreads();
+    // phase 2: wino4_filter_kernel's own code on the same vector type (one thread per float4 chunk), so that both produce the same bits
+    // (dealing the six output rows to three waves changed nothing measurable -- 84 against 85 us -- and the compiler's FMA choices with it)
+    if (threadIdx.x < 64) {
+      float4 t[6][3];
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        float4 col[3], o[6];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) col[aa] = taps[aa * 3 + bb][threadIdx.x];
+        g6(col, o);
+#pragma unroll
+        for (int aa = 0; aa < 6; ++aa) t[aa][bb] = o[aa];
+      }
+      float4* dst = reinterpret_cast<float4*>(wz.u[layer]) + j0 + threadIdx.x;
+#pragma unroll
+      for (int aa = 0; aa < 6; ++aa) {
+        float4 o[6];
+        g6(t[aa], o);
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb) dst[(long long)(6 * aa + bb) * cn4] = o[bb];
+      }
+    }
+    return;
+  }
+  const long long stride = (long long)(wz.n > 0 ? wz.sweep_blocks : gridDim.x) * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    bool skip = false;
+    for (int l = 0; l < wz.n; ++l) skip |= i >= wz.off4[l] && i < wz.off4[l] + 9ll * wz.cn4[l];
+    if (skip) continue;                          // a Winograd layer's kernel: updated by its own workgroups
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    adam_one(pp, g4[i], mm, vv, lr_t, b1, b2, eps, gs);
+    p4[i] = pp;
+    m4[i] = mm;
+    v4[i] = vv;
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (aff_shift != nullptr && i >= aff_off4 && i < aff_off4 + aff_n4) {
       const long long j = i - aff_off4;
       const float4 a = reinterpret_cast<const float4*>(aff_scale)[j], c = reinterpret_cast<const float4*>(aff_t0)[j];
@@ -691,7 +759,7 @@ extern "C" int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, f
   // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (keras.optimizers.Adam.get_updates)
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
-                     beta1, beta2, eps, grad_scale, (int)zero_grad, 0ll, 0ll, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                     beta1, beta2, eps, grad_scale, (int)zero_grad, 0ll, 0ll, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, AdamWino{});
   RADNET_CHECK_LAUNCH(ctx, "adam");
   return RADNET_OK;
 }
@@ -707,8 +775,47 @@ extern "C" int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, floa
   if (t < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: step counter starts at 1");
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
-                     beta1, beta2, eps, grad_scale, (int)zero_grad, (long long)(bias_off / 4), (long long)(bias_len / 4), scale, t0, shift);
+                     beta1, beta2, eps, grad_scale, (int)zero_grad, (long long)(bias_off / 4), (long long)(bias_len / 4), scale, t0, shift, AdamWino{});
   RADNET_CHECK_LAUNCH(ctx, "adam_affine");
+  return RADNET_OK;
+}
+
+extern "C" int radnet_adam_step_fused(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
+                                      float beta2, float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len,
+                                      const float* scale, const float* t0, float* shift, const radnet_adam_wino* layers, int32_t n_layers) {
+  if (!ctx || !p || !g || !m || !v || n_layers < 0 || n_layers > 4 || (n_layers > 0 && !layers)) return RADNET_ERR_ARG;
+  if (shift != nullptr && (!scale || !t0)) return RADNET_ERR_ARG;
+  if ((n % 4) || (bias_off % 4) || (bias_len % 4) || bias_off < 0 || bias_len < 0 || bias_off + bias_len > n)
+    RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: arena length %lld, bias range [%lld, +%lld) must be multiples of 4 inside the arena", (long long)n,
+                (long long)bias_off, (long long)bias_len);
+  if (shift && (((uintptr_t)scale | (uintptr_t)t0 | (uintptr_t)shift) & 15)) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: scale / t0 / shift must be 16-byte aligned");
+  if (t < 1) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam: step counter starts at 1");
+  AdamWino wz{};
+  wz.n = n_layers;
+  long long in_layers = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const radnet_adam_wino& d = layers[l];
+    const int64_t len = 9ll * d.c * d.n;
+    if (!d.u || d.c <= 0 || d.n <= 0 || (d.n & 3) || (d.off & 3) || d.off < 0 || d.off + len > n || ((uintptr_t)d.u & 15) || (int64_t)d.c * d.n / 4 >= (1ll << 28) ||
+        ((int64_t)d.c * d.n / 4) % 64)
+      RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: layer %d (offset %lld, c %d, n %d) does not describe a dense [3][3][c][n] kernel inside the arena with c*n a multiple of 256",
+                  l, (long long)d.off, d.c, d.n);
+    if (shift && d.off < bias_off + bias_len && bias_off < d.off + len) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: layer %d overlaps the bias range", l);
+    for (int k = 0; k < l; ++k)
+      if (d.off < layers[k].off + 9ll * layers[k].c * layers[k].n && layers[k].off < d.off + len) RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: layers %d and %d overlap", k, l);
+    wz.off4[l] = d.off / 4;
+    wz.cn4[l] = (int)((int64_t)d.c * d.n / 4);
+    wz.u[l] = d.u;
+    wz.unit0[l] = l == 0 ? 0 : wz.unit0[l - 1] + wz.cn4[l - 1] / 64;
+    in_layers += len / 4;
+  }
+  wz.unit0[n_layers] = n_layers ? wz.unit0[n_layers - 1] + wz.cn4[n_layers - 1] / 64 : 0;
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  const unsigned sweep = (unsigned)grid_for(std::max<long long>(n / 4 - in_layers, 1), 256, 8192);
+  wz.sweep_blocks = sweep;
+  hipLaunchKernelGGL(adam_kernel, dim3(sweep + (unsigned)wz.unit0[n_layers]), dim3(256), 0, ctx->stream, p, g, m, v, (long long)(n / 4), (float)lr_t,
+                     beta1, beta2, eps, grad_scale, (int)zero_grad, (long long)(bias_off / 4), (long long)(shift ? bias_len / 4 : 0), scale, t0, shift, wz);
+  RADNET_CHECK_LAUNCH(ctx, "adam_fused");
   return RADNET_OK;
 }
 

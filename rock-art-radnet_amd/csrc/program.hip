@@ -202,7 +202,10 @@ extern "C" int radnet_train_step(radnet_ctx* ctx, const radnet_train_desc* d, co
   auto head_update = [&]() -> int {
     int r = RADNET_OK;
     if (d->world > 1) r = radnet_allreduce_grads(ctx, d->head_opt.g, d->head_opt.n);
-    if (r == RADNET_OK)
+    if (r == RADNET_OK && d->n_head_wino > 0)
+      r = radnet_adam_step_fused(ctx, d->head_opt.p, d->head_opt.g, d->head_opt.m, d->head_opt.v, d->head_opt.n, d->head_opt.t, d->head_opt.lr, 0.9f,
+                                 0.999f, 1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1, 0, 0, nullptr, nullptr, nullptr, d->head_wino, d->n_head_wino);
+    else if (r == RADNET_OK)
       r = radnet_adam_step(ctx, d->head_opt.p, d->head_opt.g, d->head_opt.m, d->head_opt.v, d->head_opt.n, d->head_opt.t, d->head_opt.lr, 0.9f,
                            0.999f, 1e-7f, 1.0f / (float)(d->world > 0 ? d->world : 1), 1);
     if (r == RADNET_OK && d->head_shift) r = radnet_affine_vec(ctx, d->head_shift, d->head_scale, d->head_bias, d->head_t0, d->head_bias_len);

@@ -169,6 +169,11 @@ class FasterRCNNEngine:
         self.fwd_pair = os.environ.get("RADNET_NO_FWD_PAIR", "0") != "1"      # (a base plan built for the chain kernel keeps the single convs)
         # frozen stage-2 blocks: 3x3 + 1x1 expand (+ the next block's 1x1 reduce) as one call (radnet_conv_bottleneck decides per shape)
         self.bneck_fuse = os.environ.get("RADNET_NO_BNECK_FUSE", "0") != "1"
+        # the classifier's three 3x3 convs run their TRAINING forward on Winograd F(4x4,3x3) filters too; Adam #2 rewrites the transformed
+        # filters in its own pass (radnet_adam_step_fused).  The backward stays the direct form.
+        self.head_train_wino = (self.HEAD_TRAIN_WINOGRAD and self.use_winograd and os.environ.get("RADNET_NO_HEAD_TRAIN_WINOGRAD", "0") != "1"
+                                and os.environ.get("RADNET_NO_INFERENCE_WINOGRAD", "0") != "1")
+        self._adam_wino = None
         # 256 by default: the chain's static deal needs every workgroup of every concurrently running chain resident, and the
         # pipelined step runs two of them (prefetch lanes) beside the RPN and classifier lanes' launches (1 024 slots on the chip)
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
@@ -428,7 +433,7 @@ class FasterRCNNEngine:
     INFERENCE_WINOGRAD_LAYERS = tuple("res5%s_branch2b" % b for b in "abc")
 
     def _uses_winograd(self, c, inference=False):
-        listed = c.name in self.WINOGRAD_LAYERS or (inference and c.name in self.INFERENCE_WINOGRAD_LAYERS
+        listed = c.name in self.WINOGRAD_LAYERS or ((inference or getattr(self, "head_train_wino", False)) and c.name in self.INFERENCE_WINOGRAD_LAYERS
                                                     and os.environ.get("RADNET_NO_INFERENCE_WINOGRAD", "0") != "1")
         return self.use_winograd and listed and c.kh == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0
 
@@ -445,7 +450,8 @@ class FasterRCNNEngine:
     def _refresh_winograd(self, names=None):
         """Filter transform U = G g G^T of the Winograd layers (all of them, or the named ones after a weight update)."""
         for name in (names if names is not None else self.WINOGRAD_LAYERS + tuple(n for n in self.INFERENCE_WINOGRAD_LAYERS
-                                                                                   if getattr(self.convs.get(n), "wino_u", None) is not None)):
+                                                                                   if getattr(self.convs.get(n), "wino_u", None) is not None
+                                                                                   or getattr(self, "head_train_wino", False))):
             c = self.convs.get(name)
             if c is None or not self._uses_winograd(c, inference=True):
                 continue
@@ -528,6 +534,7 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
+    HEAD_TRAIN_WINOGRAD = True         # classifier 3x3 convs: Winograd forward in training too (engine_cont keeps the direct form)
     FROZEN_BASE_FUSION = True          # nn_base's stage 2 is frozen in every mode this engine runs (train.py, cont_train.py: stages 3-4 only)
 
     @staticmethod
@@ -1039,8 +1046,21 @@ class FasterRCNNEngine:
         """One Keras-2 Adam step over the arena.  zero_grad: the gradient arena is cleared in the same pass, so the
         next step's backward accumulates into zeros without a memset (arenas start zeroed, Arena.finalize)."""
         arena.t += 1
-        fused = (arena is getattr(self, "head_arena", None) and getattr(self, "head_bias_len", 0) > 0 and self.head_bias_off % 4 == 0
+        is_head = arena is getattr(self, "head_arena", None)
+        fused = (is_head and getattr(self, "head_bias_len", 0) > 0 and self.head_bias_off % 4 == 0
                  and self.head_bias_len % 4 == 0 and os.environ.get("RADNET_NO_ADAM_AFFINE", "0") != "1")
+        wino = self._head_adam_wino() if is_head and getattr(self, "head_train_wino", False) else None
+        if wino is not None:      # Adam #2 + folded shifts + the Winograd filters of the classifier's 3x3 convs, one launch
+            arr, n_l = wino
+            self.ctx.check(self.lib.radnet_adam_step_fused(
+                self.ctx.h, arena.p.data_ptr(), arena.g.data_ptr(), arena.m.data_ptr(), arena.v.data_ptr(), C.c_int64(arena.n), arena.t, C.c_float(self.lr),
+                C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0,
+                C.c_int64(self.head_bias_off if fused else 0), C.c_int64(self.head_bias_len if fused else 0),
+                self.head_scale.data_ptr() if fused else None, self.head_t0.data_ptr() if fused else None, self.head_shift.data_ptr() if fused else None,
+                arr, n_l), "radnet_adam_step_fused")
+            if fused:
+                self._head_shift_fresh = True
+            return
         if fused:       # Adam #2 and the refresh of the classifier convs' folded shifts as one launch (round 4: one launch fewer on the head lane)
             self.ctx.call("radnet_adam_step_affine", arena.p, arena.g, arena.m, arena.v, C.c_int64(arena.n), arena.t, C.c_float(self.lr),
                           C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1 if zero_grad else 0,
@@ -1053,6 +1073,35 @@ class FasterRCNNEngine:
             self._refresh_winograd(["rpn_conv1"])          # its forward runs on the transformed filter
         elif arena is getattr(self, "head_arena", None):
             self._inference_filters_stale = True           # transformed lazily, by the next inference pass (if any)
+            if getattr(self, "head_train_wino", False):    # (the fused pass above could not be used: dense-kernel check failed)
+                self._refresh_winograd(list(self.INFERENCE_WINOGRAD_LAYERS))
+                self._inference_filters_stale = False
+
+    def _head_adam_wino(self):
+        """(radnet_adam_wino[], n) of the classifier's 3x3 kernels for radnet_adam_step_fused, or None when one of them is not a dense
+        [3][3][c][n] slice of the head arena (then Adam #2 is followed by the filter transforms as launches of their own)."""
+        if self._adam_wino is None:
+            ent = []
+            for name in self.INFERENCE_WINOGRAD_LAYERS:
+                c = self.convs.get(name)
+                if c is None or c.kh != 3 or c.ldw != c.cout or c.cout % 4:
+                    ent = None
+                    break
+                if c.wino_u is None:
+                    self._refresh_winograd([name])
+                off, size = self.head_arena.offsets[name + "/kernel"]
+                if c.wino_m != 4 or off % 4 or size != 9 * c.cin * c.cout or c.weight.data_ptr() != self.head_arena.p[off:].data_ptr():
+                    ent = None
+                    break
+                ent.append((off, c.cin, c.cout, c.wino_u.data_ptr()))
+            if ent:
+                arr = (L.AdamWino * len(ent))()
+                for k, (off, ci, co, u) in enumerate(ent):
+                    arr[k].off, arr[k].c, arr[k].n, arr[k].u = off, ci, co, u
+                self._adam_wino = (arr, len(ent))
+            else:
+                self._adam_wino = False
+        return self._adam_wino or None
 
     def zero_grads(self, arena):
         self.ctx.call("radnet_fill_zero", arena.g, C.c_uint64(arena.n * 4))

@@ -21,6 +21,7 @@ from .engine import RES_STAGES, Arena, FasterRCNNEngine
 
 
 class ContEngine(FasterRCNNEngine):
+    HEAD_TRAIN_WINOGRAD = False        # cont_train.py mode: gradients flow through these layers into two optimizers; direct form kept
     WORKLOAD = "cont"            # one lane, other launch mix: the pipelined step's in-situ tables do not apply (measured: -1 %)
     supports_batched = False     # cont_train.py's step runs one image at a time (both optimizers move the shared stages)
     # stages 3 / 4 train here: gradients flow through ten Winograd layers and Adam's first steps divide by |g| + 1e-7, so the

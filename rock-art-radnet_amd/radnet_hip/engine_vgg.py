@@ -28,6 +28,7 @@ def vgg_feat_len(n):
 class VGG16Engine(FasterRCNNEngine):
     NETWORK = "vgg16"
     N_FEATURES = 512
+    HEAD_TRAIN_WINOGRAD = False  # the classifier head is two dense layers here
     supports_batched = False     # the mini-batch runs image by image (fc head plan is per feature map)
     feat_len = staticmethod(vgg_feat_len)
 

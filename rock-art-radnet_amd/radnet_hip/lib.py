@@ -83,6 +83,11 @@ class HostHooks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("subsample_anchors", SUBSAMPLE_FN), ("select_rois", SELECT_FN)]
 
 
+class AdamWino(C.Structure):
+    """Mirror of `radnet_adam_wino`: a dense [3][3][c][n] kernel inside an optimizer arena and its F(4x4,3x3) filter transform."""
+    _fields_ = [("off", C.c_int64), ("c", C.c_int32), ("n", C.c_int32), ("u", C.c_void_p)]
+
+
 class TrainDesc(C.Structure):
     """Mirror of `radnet_train_desc` (field order is the header's)."""
     _d, _i, _vp = C.c_double, C.c_int32, C.c_void_p
@@ -108,7 +113,7 @@ class TrainDesc(C.Structure):
                 ("head_dz", _vp), ("det_losses", _vp), ("dense_dw", _vp), ("dense_db", _vp), ("dfeat", _vp), ("g_last", _vp),
                 ("head_bwd_ops", C.POINTER(Op)), ("n_head_bwd", _i),
                 ("head_shift", _vp), ("head_scale", _vp), ("head_bias", _vp), ("head_t0", _vp), ("head_bias_len", C.c_int64),
-                ("tail_scratch", _vp)]
+                ("tail_scratch", _vp), ("head_wino", _vp), ("n_head_wino", C.c_int32)]
 
 
 def declared_symbols():
@@ -166,6 +171,8 @@ def load_library():
         "radnet_winograd4_output": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
         "radnet_winograd4_dy": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "radnet_winograd4_filter_grad": (C.c_int, [vp, vp, i32, i32, i32, vp, i32]),
+        "radnet_adam_step_fused": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32,
+                                            C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(AdamWino), i32]),
         "radnet_conv_wgrad": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_conv_bwd": (C.c_int, [vp, C.POINTER(ConvDesc)]),
         "radnet_conv_fwd_pair": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),

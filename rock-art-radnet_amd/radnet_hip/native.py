@@ -172,6 +172,9 @@ class NativeTrainStep:
             d.head_bias = ha.p[eng.head_bias_off:].data_ptr()
             d.head_bias_len = eng.head_bias_len
             d.tail_scratch = hp["tail_scratch"].data_ptr()
+            wino = eng._head_adam_wino() if getattr(eng, "head_train_wino", False) else None
+            if wino is not None:               # the classifier's training forward runs on Winograd filters: Adam #2 rewrites them
+                d.head_wino, d.n_head_wino = C.cast(wino[0], C.c_void_p), wino[1]
             ent = self._descs[key] = (d, buf, head, bp, rp, hp)
         return ent
 

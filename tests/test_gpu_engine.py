@@ -485,8 +485,9 @@ def test_default_config_augmentations_train_on_changing_tile_sizes(monkeypatch):
 
 def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
     """Inference head plans (DetectorModel.predict / RADNet's tile path) run the classifier's 3x3 convs as Winograd F(4x4,3x3)
-    on filters transformed once per weight change; training plans keep the direct form.  Same inputs through both: equal within
-    the stated tolerance, against the oracle too; after an Adam step on the head arena the inference pass sees the new weights."""
+    on filters transformed once per weight change; so do the training plans (round 4: Adam #2 rewrites the transformed filters in its
+    own pass, radnet_adam_step_fused) unless RADNET_NO_HEAD_TRAIN_WINOGRAD=1.  Same inputs through both: equal within the stated
+    tolerance, against the oracle too; after Adam steps on the head arena both see the new weights (oracle on the updated weights)."""
     from oracle import dense
     C, P, eng = setup
     rs = np.random.RandomState(17)
@@ -497,7 +498,7 @@ def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
     hi = eng._plan_head(R, 20, 31, Fd, training=False)
     assert [k for k, _ in hi["fwd"]].count("wino") == 3
     ht = eng._plan_head(R, 20, 31, Fd, training=True)
-    assert [k for k, _ in ht["fwd"]].count("wino") == 0
+    assert [k for k, _ in ht["fwd"]].count("wino") == (3 if eng.head_train_wino else 0)
     for hp in (hi, ht):
         hp["rois"].copy_(torch.from_numpy(rois))
         eng.head_forward(hp)
@@ -515,7 +516,12 @@ def test_inference_head_runs_winograd_and_follows_weight_updates(setup):
             eng.head_forward(hp)
         moved = rel_err(hi["pregr"].cpu().numpy(), before)
         assert moved > 1e-3, moved                                          # the update is visible ...
-        assert check(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy(), 2e-4) < 2e-4      # ... and both forms agree on it
+        assert check(hi["pregr"].cpu().numpy(), ht["pregr"].cpu().numpy(), 2e-4) < 2e-4      # ... both plans agree on it ...
+        P2 = dict(P)
+        P2.update(eng.get_weights())
+        pc2, pr2, _ = dense.head_forward(P2, F, rois, 7)                    # ... and it is the update the weights themselves received
+        for hp in (hi, ht):
+            assert check(hp["pcls"].cpu().numpy(), pc2[0], 1e-3) < 1e-3 and check(hp["pregr"].cpu().numpy(), pr2[0], 1e-3) < 1e-3
     finally:
         eng.set_weights(P)                                                  # module-scoped engine: restore
         eng.head_arena.g.zero_()

@@ -396,6 +396,46 @@ def test_adam(ctx):
     assert np.allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-8)
 
 
+def test_adam_fused_equals_adam_then_affine_then_filter_transforms(ctx):
+    """radnet_adam_step_fused (round 4): one pass = radnet_adam_step over the arena + radnet_affine_vec for the bias range +
+    radnet_winograd4_filter for the 3x3 kernels inside it, BIT FOR BIT (the native train step and the scheduler-driven one use either)."""
+    from radnet_hip import lib as L
+    rs = np.random.RandomState(23)
+    layers = [(64, 16, 16), (5000, 64, 32)]                       # (offset, c, n): dense [3][3][c][n] kernels inside the arena
+    n = 5000 + 9 * 64 * 32 + 1024
+    bias_off, bias_len = n - 256, 128
+    base = dict(p=rs.standard_normal(n).astype(np.float32), m=(0.01 * rs.standard_normal(n)).astype(np.float32),
+                v=(0.01 * rs.uniform(size=n)).astype(np.float32), g=(0.1 * rs.standard_normal(n)).astype(np.float32))
+    scale, t0 = rs.uniform(0.5, 1.5, bias_len).astype(np.float32), rs.standard_normal(bias_len).astype(np.float32)
+    sd, td = dev(scale), dev(t0)
+    args = lambda t: (C.c_int64(n), t, C.c_float(1e-3), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(0.5), 1)
+
+    def run(fused):
+        a = {k: dev(v) for k, v in base.items()}
+        shift = torch.zeros(bias_len, device="cuda")
+        us = [torch.full((36, c, nn), float("nan"), device="cuda") for _, c, nn in layers]
+        for t in (1, 2):
+            a["g"].copy_(dev(base["g"]) * t)
+            if fused:
+                arr = (L.AdamWino * len(layers))()
+                for k, (off, c, nn) in enumerate(layers):
+                    arr[k].off, arr[k].c, arr[k].n, arr[k].u = off, c, nn, us[k].data_ptr()
+                ctx.check(ctx.lib.radnet_adam_step_fused(ctx.h, a["p"].data_ptr(), a["g"].data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), *args(t),
+                                                         C.c_int64(bias_off), C.c_int64(bias_len), sd.data_ptr(), td.data_ptr(), shift.data_ptr(), arr, len(layers)),
+                          "adam_fused")
+            else:
+                ctx.call("radnet_adam_step", a["p"], a["g"], a["m"], a["v"], *args(t))
+                ctx.call("radnet_affine_vec", shift, sd, a["p"][bias_off:], td, C.c_int64(bias_len))
+                for k, (off, c, nn) in enumerate(layers):
+                    ctx.call("radnet_winograd4_filter", a["p"][off:], c, nn, nn, us[k])
+        torch.cuda.synchronize()
+        return [a[k].cpu().numpy() for k in "pmvg"] + [shift.cpu().numpy()] + [u.cpu().numpy() for u in us]
+
+    for name, x, y in zip(("p", "m", "v", "g", "shift", "u0", "u1"), run(True), run(False)):
+        assert not np.isnan(x).any(), name
+        assert np.array_equal(x, y), (name, int((x != y).sum()), float(np.abs(x - y).max()))
+
+
 # ---- fp64 glue: bit-exact against vectors produced by the reference itself -------------------------------------
 def test_rpn_to_roi_golden_bit_exact(ctx):
     g = load_golden("rpn_to_roi")
