@@ -159,9 +159,13 @@ class TrainStep:
             N.comm_init(eng, self.world, rank, dist if ready else None, self.group, ctx=self._main_ctx)
             N.comm_init(eng, self.world, rank, dist if ready else None, self.group, ctx=self._comm_ctx)
             self.native_comm = True
-        except L.RadnetError as e:
+        except (L.RadnetError, RuntimeError) as e:      # (RuntimeError: the rendezvous broadcast itself failed)
             import sys
             sys.stderr.write("radnet: native RCCL exchange unavailable (%s); gradients travel through torch.distributed\n" % (e,))
+        if ready and self.world > 1:                    # one path for the whole job: every rank uses the native exchange, or none does
+            flag = torch.tensor([1 if self.native_comm else 0], dtype=torch.int32, device=eng.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            self.native_comm = bool(int(flag.item()))
 
     def _allreduce(self, arena):
         if self.native_comm and arena is self.eng.rpn_arena:
