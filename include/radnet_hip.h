@@ -250,7 +250,7 @@ int radnet_adam_step(radnet_ctx* ctx, float* p, float* g, float* m, float* v, in
 int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1, float beta2,
                             float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len, const float* scale,
                             const float* t0, float* shift);
-/* radnet_adam_step_affine (shift may be 0: no bias re-fold) that ALSO rewrites the Winograd F(4x4,3x3) filter transforms of up to four
+/* radnet_adam_step_affine (shift may be 0: no bias re-fold) that ALSO rewrites the Winograd F(4x4,3x3) filter transforms of up to twelve
  * 3x3 kernels that live in the arena -- dense [3][3][c][n] at float offset `off` -- into u [36][c][n], from the weights it has just
  * updated: the arithmetic of radnet_winograd4_filter on the new weights, in the optimizer's pass (the classifier's three 3x3 convs run
  * their training forward on U; a transform launch per layer and update cost the step what the Winograd forward gives). */

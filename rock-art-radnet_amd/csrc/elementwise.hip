@@ -351,11 +351,12 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
 // the Adam update of its share of the 9 x 64 chunks, coalesced, new weights also into LDS; phase 2, one thread per chunk: the transform
 // of its nine float4 values, wino4_filter_kernel's code, 36 coalesced 16-byte stores.  The transformed filters cost their own
 // bytes (4x the kernels') and no launch (three launches cost the classifier lane as much as the Winograd forward gives: DESIGN.md 4).
+constexpr int kAdamWinoMax = 12;
 struct AdamWino {
-  long long off4[4];     // first float4 of the layer's kernel in the arena
-  int cn4[4];            // C * N / 4: float4 chunks per tap (a multiple of 64)
-  int unit0[5];          // first workgroup (relative to the first Winograd workgroup) of each layer; [n] = their total
-  float* u[4];
+  long long off4[kAdamWinoMax];   // first float4 of the layer's kernel in the arena
+  int cn4[kAdamWinoMax];          // C * N / 4: float4 chunks per tap (a multiple of 64)
+  int unit0[kAdamWinoMax + 1];    // first workgroup (relative to the first Winograd workgroup) of each layer; [n] = their total
+  float* u[kAdamWinoMax];
   int n;
   unsigned sweep_blocks; // workgroups of the flat sweep (the Winograd workgroups follow)
 };
@@ -783,7 +784,7 @@ extern "C" int radnet_adam_step_affine(radnet_ctx* ctx, float* p, float* g, floa
 extern "C" int radnet_adam_step_fused(radnet_ctx* ctx, float* p, float* g, float* m, float* v, int64_t n, int32_t t, float lr, float beta1,
                                       float beta2, float eps, float grad_scale, int32_t zero_grad, int64_t bias_off, int64_t bias_len,
                                       const float* scale, const float* t0, float* shift, const radnet_adam_wino* layers, int32_t n_layers) {
-  if (!ctx || !p || !g || !m || !v || n_layers < 0 || n_layers > 4 || (n_layers > 0 && !layers)) return RADNET_ERR_ARG;
+  if (!ctx || !p || !g || !m || !v || n_layers < 0 || n_layers > kAdamWinoMax || (n_layers > 0 && !layers)) return RADNET_ERR_ARG;
   if (shift != nullptr && (!scale || !t0)) return RADNET_ERR_ARG;
   if ((n % 4) || (bias_off % 4) || (bias_len % 4) || bias_off < 0 || bias_len < 0 || bias_off + bias_len > n)
     RADNET_FAIL(ctx, RADNET_ERR_ARG, "adam_fused: arena length %lld, bias range [%lld, +%lld) must be multiples of 4 inside the arena", (long long)n,

@@ -12,6 +12,7 @@ What this adds to FasterRCNNEngine (train.py mode: whole base frozen):
 Nothing flows below stage 3 (conv1 / stage 2 are frozen in every mode, resnet50.py:178-195).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -24,9 +25,12 @@ class ContEngine(FasterRCNNEngine):
     HEAD_TRAIN_WINOGRAD = False        # cont_train.py mode: gradients flow through these layers into two optimizers; direct form kept
     WORKLOAD = "cont"            # one lane, other launch mix: the pipelined step's in-situ tables do not apply (measured: -1 %)
     supports_batched = False     # cont_train.py's step runs one image at a time (both optimizers move the shared stages)
-    # stages 3 / 4 train here: gradients flow through ten Winograd layers and Adam's first steps divide by |g| + 1e-7, so the
-    # 15x larger fp32 rounding of F(4x4,3x3) would show in the updates of small-gradient weights -- this mode keeps F(2x2,3x3)
-    WINOGRAD_F4_LAYERS = ()
+    # rpn_conv1 keeps F(2x2,3x3) here: its weight gradient is formed in the Winograd domain and flows on into stages 3 / 4, whose first Adam
+    # steps divide by |g| + 1e-7 -- F(4x4)'s 15x larger fp32 rounding would show in the updates of small-gradient weights.  The ten
+    # stage-3/4 3x3 layers run their FORWARD as F(4x4) (round 4; their gradients stay direct): both optimizers' passes over the shared arena
+    # rewrite the transformed filters (radnet_adam_step_fused), RADNET_CONT_DIRECT_3X3=1 brings the direct forward back.
+    WINOGRAD_F4_LAYERS = tuple("res%d%s_branch2b" % (st, bl) for st, bls in ((3, "abcd"), (4, "abcdef")) for bl in bls)
+    S34_WINOGRAD = os.environ.get("RADNET_CONT_DIRECT_3X3", "0") != "1"
 
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=2e-5, autotune=True):
         super().__init__(C_cfg, device_index, n_classes, bce_mode, lr, autotune)
@@ -88,9 +92,43 @@ class ContEngine(FasterRCNNEngine):
         else:
             ar.t2 += 1
             m, v, t = ar.m2, ar.v2, ar.t2
+        wino = self._s34_adam_wino()
+        if wino is not None:          # Adam + folded shifts + the Winograd filters of the ten 3x3 kernels, one launch
+            self.ctx.check(self.lib.radnet_adam_step_fused(
+                self.ctx.h, ar.p.data_ptr(), ar.g.data_ptr(), m.data_ptr(), v.data_ptr(), C.c_int64(ar.n), t, C.c_float(self.lr), C.c_float(0.9),
+                C.c_float(0.999), C.c_float(1e-7), C.c_float(grad_scale), 1, C.c_int64(self.s34_bias_off), C.c_int64(self.s34_bias_len),
+                self.s34_scale.data_ptr(), self.s34_t0.data_ptr(), self.s34_shift.data_ptr(), wino[0], wino[1]), "radnet_adam_step_fused")
+            return
         self.ctx.call("radnet_adam_step", ar.p, ar.g, m, v, C.c_int64(ar.n), t, C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999),
                       C.c_float(1e-7), C.c_float(grad_scale), 1)
         self.refresh_s34_shift()
+        if self.S34_WINOGRAD and self.use_winograd:
+            self._refresh_winograd([n for n in self.WINOGRAD_F4_LAYERS if n in self.convs])
+
+    def _s34_adam_wino(self):
+        """(radnet_adam_wino[], n) of the stage-3/4 3x3 kernels whose forward runs on Winograd F(4x4) filters, or None."""
+        if getattr(self, "_s34_wino", None) is None:
+            ent = []
+            if self.S34_WINOGRAD and self.use_winograd and self.s34_bias_off % 4 == 0 and self.s34_bias_len % 4 == 0:
+                for name in self.WINOGRAD_F4_LAYERS:
+                    c = self.convs.get(name)
+                    if c is None or not self._uses_winograd(c):
+                        continue
+                    if c.wino_u is None:
+                        self._refresh_winograd([name])
+                    off, size = self.s34_arena.offsets[name + "/kernel"]
+                    if c.wino_m != 4 or c.ldw != c.cout or off % 4 or size != 9 * c.cin * c.cout or (c.cin * c.cout // 4) % 64:
+                        ent = []
+                        break
+                    ent.append((off, c.cin, c.cout, c.wino_u.data_ptr()))
+            if ent and len(ent) <= 12:
+                arr = (L.AdamWino * len(ent))()
+                for k, (off, ci, co, u) in enumerate(ent):
+                    arr[k].off, arr[k].c, arr[k].n, arr[k].u = off, ci, co, u
+                self._s34_wino = (arr, len(ent))
+            else:
+                self._s34_wino = False
+        return self._s34_wino or None
 
     # ------------------------------------------------------------------------------------------ base program
     def _plan_base(self, nb, H, W, slot=0):
@@ -130,7 +168,12 @@ class ContEngine(FasterRCNNEngine):
                         ops.append(("conv", ds))
                 else:
                     sc = cur
-                bb = buf(nb, oh, ow, f2); db, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", db))
+                bb = buf(nb, oh, ow, f2)
+                if st >= 3 and self.S34_WINOGRAD:      # trainable 3x3: Winograd forward on filters the optimizers keep transformed
+                    op_b, db = self._fwd_op(cb, a, nb, oh, ow, bb, keep)
+                    ops.append(op_b)
+                else:
+                    db, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", db))
                 if first and st >= 3:
                     ops.append(("conv", ds))
                 out = buf(nb, oh, ow, f3); dc, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", dc))
