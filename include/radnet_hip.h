@@ -367,7 +367,7 @@ int radnet_relu_mask(radnet_ctx* ctx, float* g, const float* act, int64_t n);
  *   WINO         p: x, v, u, m, scale|0, shift|0, y      i: nb, h, w, c, n, tiles, act, ldy, form   (radnet_winograd_input + 16
  *   WINO_REUSE   same, v already holds this input's transform                             GEMMs + radnet_winograd_output;
  *                                                                         form 4: the radnet_winograd4_* transforms, 36 GEMMs)
- *   WINO_WGRAD   p: dy, v, dz, du, dw        i: nb, h, w, c, n, ld_dy, tiles, ldw, accumulate mode (as radnet_conv_desc), form
+ *   WINO_WGRAD   p: dy, v, dz, du, dw, gscale|0   i: nb, h, w, c, n, ld_dy, tiles, ldw, accumulate mode (as radnet_conv_desc), form
  *   SCATTER      p: src, mask|0, dst         i: nb, oh, ow, c, stride, h, w
  *   FILL0        p: dst                      i: bytes (low 32 bits), bytes (high 32 bits)
  *   RELU_MASK    p: g, act                   i: n (low), n (high)

@@ -51,6 +51,7 @@ int run_wino_wgrad(radnet_ctx* ctx, const radnet_op& o) {
   float* dZ = (float*)o.p[2];
   float* dU = (float*)o.p[3];
   float* dw = (float*)o.p[4];
+  const float* gscale = (const float*)o.p[5];       // per-output-channel factor on dy (frozen BN scale of a res block conv) or null
   const int nb = o.i[0], h = o.i[1], w = o.i[2], c = o.i[3], n = o.i[4], ld_dy = o.i[5], T = o.i[6], ldw = o.i[7], mode = o.i[8];
   const int timed = ctx->timing;
   if (timed) {
@@ -58,7 +59,7 @@ int run_wino_wgrad(radnet_ctx* ctx, const radnet_op& o) {
     ctx->timing = 0;
   }
   const bool f4 = o.i[9] == 4;
-  int rc = f4 ? radnet_winograd4_dy(ctx, dy, nb, h, w, n, ld_dy, nullptr, dZ) : radnet_winograd_dy(ctx, dy, nb, h, w, n, ld_dy, nullptr, dZ);
+  int rc = f4 ? radnet_winograd4_dy(ctx, dy, nb, h, w, n, ld_dy, gscale, dZ) : radnet_winograd_dy(ctx, dy, nb, h, w, n, ld_dy, gscale, dZ);
   if (rc == RADNET_OK) rc = radnet_wgrad_batched(ctx, V, dZ, dU, f4 ? 36 : 16, T, c, n, 0);
   if (rc == RADNET_OK)
     rc = f4 ? radnet_winograd4_filter_grad(ctx, dU, c, n, ldw, dw, mode == 1 ? 1 : 0) : radnet_winograd_filter_grad(ctx, dU, c, n, ldw, dw, mode == 1 ? 1 : 0);

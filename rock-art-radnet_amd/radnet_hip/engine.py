@@ -179,6 +179,8 @@ class FasterRCNNEngine:
         self.chain_wgs = int(os.environ.get("RADNET_CHAIN_WGS", "256"))
         self._chain_plans = []     # plans whose base forward is a chain launch: check_chains() reads their sticky error words
         self.wino_wgrad = os.environ.get("RADNET_NO_WINOGRAD_WGRAD", "0") != "1"
+        # ... and their weight gradients in the Winograd domain, on the transformed input the forward pass left (the rpn_conv1 path)
+        self.head_wino_wgrad = self.head_train_wino and self.wino_wgrad and os.environ.get("RADNET_NO_HEAD_WINO_WGRAD", "0") != "1"
         self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.dev)         # split-K partials
         self.ctx.check(self.lib.radnet_set_workspace(self.ctx.h, self.ws.data_ptr(), self.ws.numel()), "set_workspace")
         # 0 off / 1 measure every new GEMM shape / 2 adopt the nearest measured M first (variable tile sizes, lib header)
@@ -534,6 +536,7 @@ class FasterRCNNEngine:
         self._plans[key] = plan
         return plan
 
+    HEAD_WINO_WGRAD_MIN_ROIS = int(os.environ.get("RADNET_HEAD_WINO_WGRAD_MIN_ROIS", "40"))
     HEAD_TRAIN_WINOGRAD = True         # classifier 3x3 convs: Winograd forward in training too (engine_cont keeps the direct form)
     FROZEN_BASE_FUSION = True          # nn_base's stage 2 is frozen in every mode this engine runs (train.py, cont_train.py: stages 3-4 only)
 
@@ -784,9 +787,9 @@ class FasterRCNNEngine:
                 for j, v in enumerate((nb, hh, ww, c, n, T, act, ldy, form)):
                     o.i[j] = v
             elif kind == "wino_wgrad":
-                dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, form, mode = p
+                dy, nb, hh, ww, c, n, ld_dy, V, dZ, dU, T, dw, ldw, form, gscale, mode = p
                 o.kind = L.OP_WINO_WGRAD
-                for j, v in enumerate((dy, V, dZ, dU, dw)):
+                for j, v in enumerate((dy, V, dZ, dU, dw, gscale)):
                     o.p[j] = ptr(v)
                 for j, v in enumerate((nb, hh, ww, c, n, ld_dy, T, ldw, mode, form)):
                     o.i[j] = v
@@ -976,7 +979,7 @@ class FasterRCNNEngine:
             dU = torch.empty(P, c1.cin, c1.cout, dtype=torch.float32, device=dev)
             wino_keep += [dZ, dU]
             wg1 = ("wino_wgrad", [dh.data_ptr(), nb, fh, fw, c1.cin, c1.cout, 512, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T,
-                                  c1.dweight.data_ptr(), c1.ldw, c1.wino_m, 1])
+                                  c1.dweight.data_ptr(), c1.ldw, c1.wino_m, None, 1])
         else:
             wg1 = ("wgrad", b1)
         bwd = [("wgrad", b2), ("colsum", [dz.data_ptr(), M, RPN_LD, RPN_LD, None, ch.dbias.data_ptr(), 1]),
@@ -1077,6 +1080,18 @@ class FasterRCNNEngine:
                 self._refresh_winograd(list(self.INFERENCE_WINOGRAD_LAYERS))
                 self._inference_filters_stale = False
 
+    def _wino_wgrad_op(self, c, V, dy, ld_dy, nb, h, w, shared):
+        """Weight gradient of a Winograd layer in the transformed domain, on the V its forward pass left: dy transform, one batched
+        reduction over the tiles, filter-gradient transform (the rpn_conv1 path; bias gradient = the colsum that follows)."""
+        T = V.shape[1]
+        P = (c.wino_m + 2) ** 2
+        key = (P, T, c.cin, c.cout)
+        if key not in shared:
+            shared[key] = (torch.empty(P, T, c.cout, dtype=torch.float32, device=self.dev), torch.empty(P, c.cin, c.cout, dtype=torch.float32, device=self.dev))
+        dZ, dU = shared[key]
+        return ("wino_wgrad", [dy.data_ptr(), nb, h, w, c.cin, c.cout, ld_dy, V.data_ptr(), dZ.data_ptr(), dU.data_ptr(), T, c.dweight.data_ptr(), c.ldw,
+                               c.wino_m, c.scale.data_ptr() if c.scale is not None else None, 1])
+
     def _head_adam_wino(self):
         """(radnet_adam_wino[], n) of the classifier's 3x3 kernels for radnet_adam_step_fused, or None when one of them is not a dense
         [3][3][c][n] slice of the head arena (then Adam #2 is followed by the filter transforms as launches of their own)."""
@@ -1155,12 +1170,17 @@ class FasterRCNNEngine:
             else:
                 fwd.append(("conv", da))
             bb = buf(R, oh, ow, f2)
+            n_keep = len(keep)
             op_b, db = self._fwd_op(cb, a, R, oh, ow, bb, keep, relu=True, inference=not training)
             fwd.append(op_b)
+            # V of the forward pass, for the weight gradient in the Winograd domain -- where the pass is large enough for it to pay: measured
+            # 554.6 against 579.9 images/s at 20 RoIs (four launches instead of a share of the paired one, on the saturated lane), 667.7 against
+            # 654.5 at 2 x 20 (per-GPU batch 2)
+            wino_v = keep[n_keep] if (training and op_b[0] == "wino" and self.head_wino_wgrad and R >= self.HEAD_WINO_WGRAD_MIN_ROIS) else None
             if first and not self.fwd_pair:
                 fwd.append(("conv", ds))
             out = buf(R, oh, ow, f3); dc, _, _ = self._desc(cc, bb, R, oh, ow, out, relu=True, addend=sc); fwd.append(("conv", dc))
-            blocks.append(dict(first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, names=(b + "2a", b + "2b", b + "2c", b + "1")))
+            blocks.append(dict(first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, names=(b + "2a", b + "2b", b + "2c", b + "1"), wino_v=wino_v))
             cur, h, w = out, oh, ow
         M = R * h * w
         feat = buf(R, 2048)
@@ -1177,6 +1197,7 @@ class FasterRCNNEngine:
         dfeat = buf(R, 2048)
         # backward program (train.py mode: nothing flows below the RoI crop, the base is frozen)
         bwd = []
+        shared_wg = {}                         # dZ / dU scratch of the Winograd-domain weight gradients: one set for layers of one shape
         bwd_parts = []                         # the same program cut per block, last block first (bucketed gradient exchange)
         g_out = buf(M, f3)                     # gradient w.r.t. the last block's output, ReLU mask applied
         g_first = g_out
@@ -1202,7 +1223,8 @@ class FasterRCNNEngine:
             dC = bdesc(B["dc"], cc, g_out, f3, g_b, f2, None, B["b"])
             bwd += [("wgrad", dC), ("colsum", [g_out.data_ptr(), M, f3, f3, cc.scale.data_ptr(), cc.dbias.data_ptr(), 1]), ("dgrad", dC)]
             dB = bdesc(B["db"], cb, g_b, f2, g_a, f1, None, B["a"])
-            bwd += [("wgrad", dB), ("colsum", [g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr(), 1]), ("dgrad", dB)]
+            wg_b = self._wino_wgrad_op(cb, B.get("wino_v"), g_b, f2, R, B["db"].oh, B["db"].ow, shared_wg) if B.get("wino_v") is not None else None
+            bwd += [wg_b or ("wgrad", dB), ("colsum", [g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr(), 1]), ("dgrad", dB)]
             if B["first"]:
                 dA = bdesc(B["da"], ca, g_a, f1)
                 bwd += [("wgrad", dA), ("colsum", [g_a.data_ptr(), M, f1, f1, ca.scale.data_ptr(), ca.dbias.data_ptr(), 1])]
@@ -1227,7 +1249,7 @@ class FasterRCNNEngine:
         live = torch.ones(groups, dtype=torch.int32, device=dev)
         keep.append(live)
         plan = dict(R=R, rois=rois, pooled=pooled, fwd=fwd, bwd=bwd, bwd_parts=bwd_parts, blocks=blocks, y5=cur, hw=h * w, M=M, feat=feat, pcls=pcls,
-                    tail_scratch=tail_scratch, live=live, live_host=[1] * groups,
+                    tail_scratch=tail_scratch, live=live, live_host=[1] * groups, wg_scratch=shared_wg,
                     pregr=pregr, y1=y1, y2=y2, dz=dz, dfeat=dfeat, g_last=g_first, F=F, fh=fh, fw=fw, keep=keep, groups=groups)
         self._plans[key] = plan
         return plan

@@ -31,6 +31,9 @@ class ContEngine(FasterRCNNEngine):
     # rewrite the transformed filters (radnet_adam_step_fused), RADNET_CONT_DIRECT_3X3=1 brings the direct forward back.
     WINOGRAD_F4_LAYERS = tuple("res%d%s_branch2b" % (st, bl) for st, bls in ((3, "abcd"), (4, "abcdef")) for bl in bls)
     S34_WINOGRAD = os.environ.get("RADNET_CONT_DIRECT_3X3", "0") != "1"
+    # their weight gradients in the Winograd domain too (rpn_conv1's path): measured SLOWER here -- 134.2 against 138.9 images/s: three
+    # launches + a column sum + the unpaired data gradient against one paired launch per layer -- off unless RADNET_CONT_WINO_WGRAD=1
+    S34_WINO_WGRAD = os.environ.get("RADNET_CONT_WINO_WGRAD", "0") == "1"
 
     def __init__(self, C_cfg, device_index=0, n_classes=None, bce_mode=0, lr=2e-5, autotune=True):
         super().__init__(C_cfg, device_index, n_classes, bce_mode, lr, autotune)
@@ -169,16 +172,20 @@ class ContEngine(FasterRCNNEngine):
                 else:
                     sc = cur
                 bb = buf(nb, oh, ow, f2)
+                wino_v = None
                 if st >= 3 and self.S34_WINOGRAD:      # trainable 3x3: Winograd forward on filters the optimizers keep transformed
+                    n_keep = len(keep)
                     op_b, db = self._fwd_op(cb, a, nb, oh, ow, bb, keep)
                     ops.append(op_b)
+                    if op_b[0] == "wino" and self.wino_wgrad and self.S34_WINO_WGRAD:
+                        wino_v = keep[n_keep]          # the transformed input: the weight gradient is formed on it (rpn_conv1's path)
                 else:
                     db, _, _ = self._desc(cb, a, nb, oh, ow, bb); ops.append(("conv", db))
                 if first and st >= 3:
                     ops.append(("conv", ds))
                 out = buf(nb, oh, ow, f3); dc, _, _ = self._desc(cc, bb, nb, oh, ow, out, relu=True, addend=sc); ops.append(("conv", dc))
                 if st >= 3:
-                    blocks.append(dict(st=st, first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, h=h, w=w, oh=oh, ow=ow,
+                    blocks.append(dict(st=st, first=first, x=cur, a=a, b=bb, out=out, da=da, db=db, dc=dc, ds=ds, h=h, w=w, oh=oh, ow=ow, wino_v=wino_v,
                                        cin=ca.cin, f=(f1, f2, f3), stride=ca.stride, names=(b + "2a", b + "2b", b + "2c", b + "1")))
                 cur, h, w = out, oh, ow
         F = cur
@@ -227,7 +234,12 @@ class ContEngine(FasterRCNNEngine):
             dC = self._bdesc(B["dc"], cc, g_out, f3, g_b, f2, None, B["b"])
             bwd += [("wgrad", dC), ("dgrad", dC)]
             dB = self._bdesc(B["db"], cb, g_b, f2, g_a, f1, None, B["a"])
-            bwd += [("wgrad", dB), ("dgrad", dB)]
+            if B.get("wino_v") is not None:        # weight gradient in the Winograd domain (4x fewer flops), bias gradient as a column sum
+                self._wg_scratch = getattr(self, "_wg_scratch", {})
+                bwd += [self._wino_wgrad_op(cb, B["wino_v"], g_b, f2, nb, B["oh"], B["ow"], self._wg_scratch),
+                        ("colsum", [g_b.data_ptr(), M, f2, f2, cb.scale.data_ptr(), cb.dbias.data_ptr(), 1]), ("dgrad", dB)]
+            else:
+                bwd += [("wgrad", dB), ("dgrad", dB)]
             if B["first"]:
                 cs = self.convs[B["names"][3]]
                 dA = self._bdesc(B["da"], ca, g_a, f1)
