@@ -29,3 +29,18 @@ rm -rf gpurun_out/$TAG/pmc1 gpurun_out/$TAG/pmc2 gpurun_out/$TAG/pmc3 gpurun_out
 bash tools/rpn_gemm_traffic.sh gpurun_out/$TAG/rpn_traffic > gpurun_out/$TAG/rpn_gemm_traffic.txt 2>&1 || true
 rm -rf gpurun_out/$TAG/rpn_traffic
 head -14 gpurun_out/$TAG/trace_summary.txt; head -16 gpurun_out/$TAG/pmc_summary.txt | cut -c1-220; cat gpurun_out/$TAG/rpn_gemm_traffic.txt
+# the other bench lines (BASELINE cfg 3 / cfg 5 / cont_train.py mode / cfg 4 on one GPU / the data-parallel schedule rehearsed with 1-rank communicators)
+for w in predict vgg16 cont; do python bench.py --workload $w > gpurun_out/$TAG/bench_$w.json 2> gpurun_out/$TAG/bench_$w.err; done
+python bench.py --per-gpu-batch 2 --no-cpu-baseline > gpurun_out/$TAG/bench_per_gpu_batch2_ordered.json 2>/dev/null
+RADNET_DETERMINISTIC=0 python bench.py --per-gpu-batch 2 --no-cpu-baseline > gpurun_out/$TAG/bench_per_gpu_batch2_atomics.json 2>/dev/null
+RADNET_BENCH_REHEARSAL=nccl1 python bench.py --no-cpu-baseline > gpurun_out/$TAG/bench_dp_rehearsal_native_exchange.json 2>/dev/null
+python bench.py --no-cpu-baseline > gpurun_out/$TAG/bench_same_box_as_dp_rehearsal.json 2>/dev/null
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("gpurun_out/$TAG/bench*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]
+        print(f.split("/")[-1], round(d["value"], 1), d["unit"], round(d["ms_per_step"], 3), round(r["frac"], 3), round(r.get("executed_frac") or 0, 3))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
