@@ -537,6 +537,7 @@ class FasterRCNNEngine:
         return plan
 
     HEAD_WINO_WGRAD_MIN_ROIS = int(os.environ.get("RADNET_HEAD_WINO_WGRAD_MIN_ROIS", "40"))
+    CROP_AHEAD = True                  # TrainStep may issue head_crop() ahead of head_forward(cropped=True)
     HEAD_TRAIN_WINOGRAD = True         # classifier 3x3 convs: Winograd forward in training too (engine_cont keeps the direct form)
     FROZEN_BASE_FUSION = True          # nn_base's stage 2 is frozen in every mode this engine runs (train.py, cont_train.py: stages 3-4 only)
 
@@ -1276,7 +1277,18 @@ class FasterRCNNEngine:
                 self._head_slices = sl[::-1]
         return self._head_slices
 
-    def head_forward(self, hp, training=False, loss_out=None, group_live=None):
+    def head_crop(self, hp):
+        """RoiPoolingConv (RoiPoolingConv.py:48-88) of the plan's RoIs: the first launch of the classifier pass.  TrainStep issues it on the
+        RPN lane right after the host's sample selection (head_forward(cropped=True) then starts at stage 5)."""
+        G = hp.get("groups", 1)
+        if G == 1:
+            self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
+        else:
+            rg = hp["R"] // G
+            for g in range(G):                  # RoIs of image g crop feature map g
+                self.ctx.call("radnet_roi_resize_fwd", hp["F"][g], hp["fh"], hp["fw"], 1024, hp["rois"][g * rg:], rg, 14, hp["pooled"][g * rg:])
+
+    def head_forward(self, hp, training=False, loss_out=None, group_live=None, cropped=False):
         """classifier_layer forward (`training` only matters for the VGG16 head's Dropout).  loss_out (training plans whose
         targets y1 / y2 are already packed): the detector losses (row g of loss_out for group g: cls, regr, accuracy) and the
         gradient w.r.t. the logits are computed in the same launch as the dense heads (csrc/head_tail.hip); head_backward
@@ -1284,12 +1296,8 @@ class FasterRCNNEngine:
         G = hp.get("groups", 1)
         if "live" not in hp:
             self.sync_inference_filters()
-        if G == 1:
-            self.ctx.call("radnet_roi_resize_fwd", hp["F"], hp["fh"], hp["fw"], 1024, hp["rois"], hp["R"], 14, hp["pooled"])
-        else:
-            rg = hp["R"] // G
-            for g in range(G):                  # RoIs of image g crop feature map g
-                self.ctx.call("radnet_roi_resize_fwd", hp["F"][g], hp["fh"], hp["fw"], 1024, hp["rois"][g * rg:], rg, 14, hp["pooled"][g * rg:])
+        if not cropped:
+            self.head_crop(hp)
         self._run(hp["fwd"])
         hp["_tail_fused"] = False
         if self.fuse_tail:

@@ -29,6 +29,7 @@ class VGG16Engine(FasterRCNNEngine):
     NETWORK = "vgg16"
     N_FEATURES = 512
     HEAD_TRAIN_WINOGRAD = False  # the classifier head is two dense layers here
+    CROP_AHEAD = False           # (its head_forward crops 7x7 itself)
     supports_batched = False     # the mini-batch runs image by image (fc head plan is per feature map)
     feat_len = staticmethod(vgg_feat_len)
 

@@ -99,6 +99,7 @@ class TrainStep:
         self._slots = 0                  # batches started: buffer set = count % NBUF
         # pipelined mode (step(next_batch=...)): the engine's lanes run three batches' phases side by side
         self.side_prefetch = os.environ.get("RADNET_SIDE_PREFETCH", "1") == "1" and hasattr(eng, "lane")
+        self.crop_ahead = os.environ.get("RADNET_NO_CROP_AHEAD", "0") != "1"       # pipelined step: RoI packing + crop-resize on the RPN lane
         # per-GPU mini-batch (BASELINE cfg 4) as ONE layer program: base / RPN / stage-5 GEMMs run once with the images
         # stacked along M (RADNET_BATCHED=0: image by image, the round-1 path)
         self.batched = os.environ.get("RADNET_BATCHED", "1") == "1" and getattr(eng, "supports_batched", False)
@@ -552,6 +553,28 @@ class TrainStep:
                 view = eng.rpn_image(st["rps"][0], i) if st.get("stacked") else st["rps"][i]
                 self.capture.append(dict(pred=view["pred"].cpu().numpy().copy(), R=R[:n].cpu().numpy().copy(),
                                          keep=(cls >= 0).copy(), cls=cls.copy(), sel_kept=list(sel_k)))
+        # ---- pipelined: RoI packing + crop-resize of THIS batch on the RPN lane, now -- the lane is idle until the host has subsampled the
+        # next batch's anchors (0.3 ms), and the classifier lane, the saturated one, starts at stage 5 (two launches fewer on it)
+        crop_ev = None
+        live_now = [i for i in range(nloc) if picks[i] is not None]
+        if pipelined and self.crop_ahead and live_now and getattr(eng, "CROP_AHEAD", False):
+            after(self._head_done.get(st["slot"]))      # the classifier phase that last used this buffer set's head plan
+            if st.get("stacked"):
+                bp0 = st["plans"][0]
+                hp0 = eng._plan_head(nloc * C.n_rois, bp0["fh"], bp0["fw"], bp0["F"], groups=nloc)
+                for i in range(nloc):
+                    if picks[i] is None:
+                        eng.idle_roi_group(hp0, i)
+                    else:
+                        eng.pack_roi_batch(picks[i][0], picks[i][1], hp0, group=i)
+                eng.head_crop(hp0)
+            else:
+                for i in live_now:
+                    bp0 = st["plans"][i]
+                    hp0 = eng._plan_head(C.n_rois, bp0["fh"], bp0["fw"], bp0["F"])
+                    eng.pack_roi_batch(picks[i][0], picks[i][1], hp0)
+                    eng.head_crop(hp0)
+            crop_ev = eng.mark()
         # ---- pipelined: the next batch's RPN phase goes first -- the host sync of the NEXT call waits for it
         if pipelined:
             self._rpn_phase(nxt, ntot, mark)           # its RPN forward is already enqueued (above)
@@ -572,6 +595,8 @@ class TrainStep:
             works.append(allreduce_grad_arena_start(eng.head_arena.g[lo:hi], self.world, self.group_head))
 
         with head_lane():      # what it reads from the other lanes (feature map, RoI labels) is complete: the host waited
+            after(crop_ev)
+            crop_kw = {"cropped": True} if crop_ev is not None else {}
             if st.get("stacked") and live:
                 # per-GPU mini-batch: all images' RoIs through stage 5 in ONE pass (GEMM M = nloc * n_rois * 49); losses per
                 # image, an image without a classifier step contributes zero gradient rows
@@ -580,15 +605,17 @@ class TrainStep:
                 slots = []
                 for i in range(nloc):
                     if picks[i] is None:
-                        eng.idle_roi_group(hp, i)
+                        if crop_ev is None:
+                            eng.idle_roi_group(hp, i)
                         slots.append(None)
                     else:
-                        eng.pack_roi_batch(picks[i][0], picks[i][1], hp, group=i)
+                        if crop_ev is None:
+                            eng.pack_roi_batch(picks[i][0], picks[i][1], hp, group=i)
                         slots.append(self._det_l[slot][i])            # row i = image i of the mini-batch
                         n_head += 1
                 det_rows = [i for i in range(nloc) if picks[i] is not None]
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
-                eng.head_forward(hp, training=True, loss_out=self._det_l[slot], group_live=[p is not None for p in picks])
+                eng.head_forward(hp, training=True, loss_out=self._det_l[slot], group_live=[p is not None for p in picks], **crop_kw)
                 eng.set_accumulate(hp["bwd"], False, prezeroed=True)
                 eng.head_backward(hp, accumulate=True, loss_out=slots, on_part=exchange if bucketed else None)
                 for i in det_rows:
@@ -597,9 +624,10 @@ class TrainStep:
                 if picks[i] is None:
                     continue
                 hp = eng._plan_head(C.n_rois, bp["fh"], bp["fw"], bp["F"])
-                eng.pack_roi_batch(picks[i][0], picks[i][1], hp)
+                if crop_ev is None:
+                    eng.pack_roi_batch(picks[i][0], picks[i][1], hp)
                 self._finish_head_update()               # deferred Adam #2 of the previous step: head weights are read next
-                eng.head_forward(hp, training=True, loss_out=self._det_l[slot][n_head])
+                eng.head_forward(hp, training=True, loss_out=self._det_l[slot][n_head], **crop_kw)
                 eng.set_accumulate(hp["bwd"], n_head > 0, prezeroed=True)
                 if bucketed and i == live[-1]:
                     eng.head_backward(hp, accumulate=True, loss_out=self._det_l[slot][n_head], on_part=exchange)
