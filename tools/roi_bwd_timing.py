@@ -1,5 +1,6 @@
-"""radnet_roi_resize_bwd alone on the chip: ordered form (RADNET_ROI_BWD_WAVES waves per workgroup) against the atomics form, 20 RoIs of
-the sizes the RPN proposes on the 38x63 map, 14x14 crops, 1024 channels.  usage: python tools/roi_bwd_timing.py"""
+"""radnet_roi_resize_bwd alone on the chip: ordered form (a gather per feature-map pixel since round 4: 41 us; the row-in-LDS form before it
+155-165 us with 1, 2 or 4 waves per row) against the atomics form (50 us), 20 RoIs of the sizes the RPN proposes on the 38x63 map, 14x14 crops,
+1024 channels.  usage: python tools/roi_bwd_timing.py"""
 import os
 import sys
 
@@ -33,8 +34,7 @@ def main():
             ctx.call("radnet_roi_resize_bwd", dy, H, W, C, rd, R, ps, dF)
         e1.record()
         torch.cuda.synchronize()
-        print("%s (waves %s): %.1f us per call" % ("ordered" if det else "atomics", os.environ.get("RADNET_ROI_BWD_WAVES", "default") if det else "-",
-                                                    e0.elapsed_time(e1) * 1e3 / 50), flush=True)
+        print("%s: %.1f us per call" % ("ordered (gather per pixel)" if det else "atomics", e0.elapsed_time(e1) * 1e3 / 50), flush=True)
 
 
 if __name__ == "__main__":
